@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- SSIMULACRA2 scorer throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one pass of the hot path over one batch of synthetic input: one SSIMULACRA2
+score of one (ref, dist) pair of 3840x2160 8-bit RGB frames (BASELINE.json configs[1],
+"Single 3840x2160 8-bit RGB, --score-tgt 80 --max-pass 6, SSIMULACRA2 on 1 MI355X"), both
+frames already resident in HBM when the timed region starts.  With N ranks every rank
+scores its own pair per step (independent images shard with no data-path collective:
+weak scaling); the only collective is the final RCCL all_gather of the per-rank result
+records.  value = megapixels (scale-0 pixels of one image) scored per second, whole job.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (scale-0 fused kernel): algorithmic bytes of SURVEY.md
+                  8(d)'s W-model for the stages that kernel covers, divided by its average
+                  launch time measured live with HIP events on the kernel's own stream.
+  cpu_baseline -- the repo's CPU oracle ("port"; the reference's Zig+fssimu2 path cannot be
+                  built: no Zig, fssimu2 source absent) timed on this host, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 3840, 2160
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# SURVEY.md 8(d) W-model, bytes per scale-0 pixel, for what the scale-0 kernel covers in
+# the algorithmic model: read u8 RGB of both frames (6), write XYB_0 of both (24), blur
+# stage reads XYB_0 of both (24).  (The 2x2 downsample to scale 1 -- 6 B/px written -- is
+# a separate kernel in this round and is not credited to this kernel.)
+ALGO_BYTES_PER_PX_SCALE0 = 6 + 24 + 24
+# whole score, all six scales: 85.97 B per scale-0 pixel
+ALGO_BYTES_PER_PX_SCORE = 85.97
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            return 2
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import oavif_amd
+    from oavif_amd import synth
+
+    w, h = args.width, args.height
+    mp = w * h / 1e6
+    # synthetic pair of this rank (seeded): structured frame + 8x8 block quantisation
+    ref = synth.make_ref(w, h, seed=rank)
+    dst = synth.distort(ref, "blockq", 2)
+    t_ref = torch.from_numpy(ref).cuda()
+    t_dst = torch.from_numpy(dst).cuda()
+    torch.cuda.synchronize()
+
+    scorer = oavif_amd.Ssimu2(local_rank)
+    p_ref, p_dst = t_ref.data_ptr(), t_dst.data_ptr()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    score = None
+    for _ in range(args.warmup):
+        scorer.enqueue_device(p_ref, p_dst, w, h)
+    if args.warmup:
+        score = scorer.wait()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scorer.enqueue_device(p_ref, p_dst, w, h)
+    score = scorer.wait()          # drains the ctx stream (all K scores)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rec = torch.tensor([float(rank), float(score), elapsed], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)   # the final RCCL gather of per-rank result records
+        scores = [float(g[1]) for g in gathered]
+    else:
+        scores = [float(score)]
+    t = float(t_max.item())
+
+    if rank == 0:
+        value = world * args.steps * mp / t
+        out = {
+            "metric": "ssimulacra2_megapixels_per_sec",
+            "value": round(value, 2),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(t / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ssimulacra2 score of one {w}x{h} RGB8 (ref, dist) pair per "
+                                   f"step per GPU, inputs resident in HBM (BASELINE configs[1])",
+                       "width": w, "height": h, "pairs_per_step": world,
+                       "parallelism": f"image-per-gpu x{world}" if world > 1 else "single gpu",
+                       "kernels": oavif_amd.version()},
+            "scores": [round(s, 6) for s in scores],
+        }
+
+        # ---- roofline of the dominant kernel, measured live with HIP events ----------------
+        iters = 50
+        k_ms = scorer.time_scale_kernel(p_ref, p_dst, w, h, 0, iters)
+        algo_bytes = ALGO_BYTES_PER_PX_SCALE0 * w * h
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("scale0_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_scale<u8> (scale 0 fused XYB+blur+maps)",
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(algo_bytes),
+                           "model": "SURVEY 8(d) W-model, scale-0 share: 54 B/px"}
+        # whole-score view (all kernels of one score, W-model 85.97 B/px)
+        ms_total, _ = scorer.time_device(p_ref, p_dst, w, h, 20)
+        score_ms = ms_total / 20
+        out["score_roofline"] = {
+            "ms_per_score_device": round(score_ms, 5),
+            "achieved": round(ALGO_BYTES_PER_PX_SCORE * w * h / (score_ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ALGO_BYTES_PER_PX_SCORE * w * h / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+        # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
+        scorer.set_reference(ref)
+        scorer.score_against_reference(dst)
+        tt = time.perf_counter()
+        n_pass = 5
+        for _ in range(n_pass):
+            scorer.score_against_reference(dst)
+        out["ms_per_search_pass_4k_gpu_side"] = round((time.perf_counter() - tt) / n_pass * 1e3, 4)
+        out["search_pass_note"] = ("pageable host dist -> H2D -> score -> D2H score; excludes the "
+                                   "CPU libaom encode / dav1d decode of the pass")
+
+        # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ssimu2_oracle as orc
+            orc.build()
+            cores = os.cpu_count() or 1
+            os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+            orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)  # spin up
+            tc = time.perf_counter()
+            reps = 0
+            cpu_score = None
+            while reps < 3 and (time.perf_counter() - tc) < 20.0:
+                cpu_score = orc.compute_ssimu2(ref, dst, orc.BLUR_FIR, omp=True)
+                reps += 1
+            dt = (time.perf_counter() - tc) / reps
+            # single-thread figure on a 1/4-area crop, scaled per pixel
+            crop_r, crop_d = ref[: h // 2, : w // 2], dst[: h // 2, : w // 2]
+            t1 = time.perf_counter()
+            orc.compute_ssimu2(crop_r, crop_d, orc.BLUR_FIR, omp=False)
+            dt1 = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(mp / dt, 3), "unit": "MP/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x the same {w}x{h} pair, oracle/ssimu2_oracle.c (FIR, "
+                          f"OpenMP, {cores} threads); not the reference's Zig+fssimu2 "
+                          f"(unbuildable here)",
+                "single_thread_value": round((w // 2) * (h // 2) / 1e6 / dt1, 3),
+                "single_thread_sample": f"1 x {w // 2}x{h // 2} crop, 1 thread",
+                "score_abs_diff_vs_hip": abs(cpu_score - scores[0])}
+        print(json.dumps(out), flush=True)
+
+    scorer.close()
+    if distributed:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

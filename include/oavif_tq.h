@@ -1,0 +1,91 @@
+/*
+ * oavif_tq.h -- C ABI of the target-quality search (host logic, fp64 scalar).
+ *
+ * Mirrors /root/reference/src/tq.zig:
+ *   TQCtx                 tq.zig:10-13   -> oavif_tq_result.{num_pass, score}
+ *   PassResult            tq.zig:16-19   -> oavif_tq_pass
+ *   computeScoreAtQuality tq.zig:21-38   -> the probe callback (encode at q -> decode ->
+ *                                           score); oavif_tq_search_hip supplies the score
+ *                                           half from the HIP scorer (ssimu2_hip.h)
+ *   predictQFromScore     tq.zig:40-43   -> oavif_tq_predict_q_from_score
+ *   interpolateQuantizer  tq.zig:73-122  -> oavif_tq_interpolate_quantizer
+ *   findTargetQuality     tq.zig:124-210 -> oavif_tq_find_target_quality
+ * The options are the three fields of AvifEncOptions the search reads
+ * (/root/reference/src/parse_args.zig:55,58,59; ranges parse_args.zig:85-86,101-104).
+ *
+ * libavif/libaom encode and dav1d decode stay on the CPU and stay the caller's: they enter
+ * through callbacks, exactly where tq.zig:24 and tq.zig:26 call io.encodeAvifToBuffer /
+ * io.decodeAvifToRgb.
+ */
+#ifndef OAVIF_TQ_H_
+#define OAVIF_TQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ssimu2_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAVIF_TQ_MAX_PASS 12 /* parse_args.zig:104 */
+
+typedef struct {
+    double score_tgt;  /* -t/--score-tgt, 30..100, default 80   (parse_args.zig:55,85-86)  */
+    double tolerance;  /* --tolerance,    1..100,  default 2    (parse_args.zig:58,101-102) */
+    uint32_t max_pass; /* --max-pass,     1..12,   default 6    (parse_args.zig:59,103-104) */
+} oavif_tq_options;
+
+typedef struct {
+    uint32_t q;   /* quantizer probed */
+    double score; /* SSIMULACRA2 score of that probe */
+} oavif_tq_pass;
+
+typedef struct {
+    uint32_t q;          /* EncCtx.q after the search: the chosen quantizer (main.zig:29)   */
+    double score;        /* TQCtx.score: score reported for the chosen q (tq.zig:12)       */
+    uint32_t num_pass;   /* TQCtx.num_pass: probes actually encoded+scored (tq.zig:11,29)  */
+    int32_t buf_q;       /* EncBuffer.q: q of the LAST probe, whose AVIF bytes the caller
+                            still holds (tq.zig:31-35); the caller re-encodes iff
+                            buf_q != q (main.zig:109-113).  -1 if no probe ran.          */
+    uint32_t history_len;
+    oavif_tq_pass history[OAVIF_TQ_MAX_PASS]; /* probes in the order they were made */
+} oavif_tq_result;
+
+/* One search pass: produce the score of quantizer `q` (tq.zig:21-38).  Return 0 on
+   success; any other value aborts the search and is returned by the search function
+   (the reference's `try` at tq.zig:150). */
+typedef int (*oavif_tq_probe_fn)(void* user, uint32_t q, double* out_score);
+
+/* Encode `q` -> decode -> tight RGB8 into out_rgb (w*h*3 bytes, caller = search owns it).
+   CPU codec of the caller (io.zig:544-636 + io.zig:638-666).  *out_avif_size receives
+   the size of the encoded AVIF (EncBuffer.size).  Return 0 on success. */
+typedef int (*oavif_tq_codec_fn)(void* user, uint32_t q, uint8_t* out_rgb, size_t* out_avif_size);
+
+void oavif_tq_default_options(oavif_tq_options* o);
+
+/* tq.zig:40-43 */
+uint32_t oavif_tq_predict_q_from_score(double tgt);
+
+/* tq.zig:73-122; history in probe order (it is copied and sorted inside). */
+uint32_t oavif_tq_interpolate_quantizer(uint32_t lo_bound, uint32_t hi_bound,
+                                        const oavif_tq_pass* history, uint32_t history_len,
+                                        double target);
+
+/* tq.zig:124-210 with the pass (tq.zig:21-38) supplied by `probe`. */
+int oavif_tq_find_target_quality(const oavif_tq_options* o, oavif_tq_probe_fn probe, void* user,
+                                 oavif_tq_result* out);
+
+/* The same search with the scorer half of every pass done by the HIP scorer: `ref_rgb`
+   (w*h*3, tight RGB8 = EncCtx.rgb) is uploaded once, each pass calls `codec` then scores
+   the decoded frame on the GPU.  Equivalent to findTargetQuality with tq.zig:37 bound to
+   ssimu2_score_rgb8. */
+int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uint8_t* ref_rgb,
+                        uint32_t w, uint32_t h, oavif_tq_codec_fn codec, void* user,
+                        oavif_tq_result* out, size_t* out_last_avif_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAVIF_TQ_H_ */

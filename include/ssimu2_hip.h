@@ -1,0 +1,111 @@
+/*
+ * ssimu2_hip.h -- C ABI of the MI355X (gfx950) SSIMULACRA2 scorer.
+ *
+ * Drop-in boundary for the single scorer call of oavif's target-quality search:
+ *
+ *     /root/reference/src/tq.zig:37
+ *         return try fssimu2.computeSsimu2(allocator, e.rgb, decoded_rgb, e.w, e.h, 3, null);
+ *
+ * (`fssimu2` = third-party Zig module, /root/reference/build.zig.zon:7-10, wired in at
+ * /root/reference/build.zig:30-33,65).  A Zig shim with that exact signature that forwards
+ * to these entry points is in oavif_amd/zig/fssimu2.zig; INTEGRATION.md shows the build
+ * wiring.  Plain pointers and sizes only; no C++/torch types cross this boundary; no
+ * exceptions; no aborts.
+ *
+ * Input contract (the reference's): `ref` and `dist` are tightly packed 8-bit interleaved
+ * RGB, row-major, w*h*3 bytes (main.zig:86, io.zig:57-133 for ref; io.zig:647-663 for dist).
+ * The caller owns both buffers; the library never frees or retains host pointers after a
+ * call returns (dist is freed by the caller right after the call: tq.zig:26-27).
+ *
+ * Threading: one ssimu2_ctx = one HIP stream + its device scratch; a ctx is not
+ * re-entrant; distinct ctxs are independent (different streams and/or devices).
+ */
+#ifndef SSIMU2_HIP_H_
+#define SSIMU2_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssimu2_ctx ssimu2_ctx;
+
+/* Return codes (0 = success).  The Zig shim maps them to Zig errors consumed by the
+   `try` at tq.zig:37. */
+enum {
+    SSIMU2_OK = 0,
+    SSIMU2_ERR_INVALID_ARG = -1,   /* null pointer, zero dimension                      */
+    SSIMU2_ERR_UNSUPPORTED = -2,   /* channels != 3 (the reference always passes 3)     */
+    SSIMU2_ERR_OOM = -3,           /* host or device allocation failed                  */
+    SSIMU2_ERR_HIP = -4,           /* a HIP runtime call or kernel launch failed        */
+    SSIMU2_ERR_NO_REFERENCE = -5,  /* score_against_reference without set_reference     */
+    SSIMU2_ERR_NO_DEVICE = -6      /* no usable gfx950 device                           */
+};
+
+/* Number of per-scale statistics and scales of the published algorithm: 6 scales x
+   (3 channels x {L1,L4} SSIM + 3 channels x {L1,L4} x {artifact, detail_lost}) = 108. */
+#define SSIMU2_NUM_SCALES 6
+#define SSIMU2_STATS_PER_SCALE 18
+
+/* Create a scorer bound to HIP device `device`.  If `hip_stream` is non-NULL it is a
+   hipStream_t owned by the caller that all work of this ctx is enqueued on; if NULL the
+   ctx creates (and later destroys) its own non-blocking stream. */
+int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx);
+void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
+
+/* Human-readable description of the last error on this ctx ("" if none).  The pointer
+   stays valid until the next call on the ctx.  ctx == NULL returns the last creation
+   error of the calling thread. */
+const char* ssimu2_last_error(const ssimu2_ctx* ctx);
+
+/* == fssimu2.computeSsimu2(allocator, ref, dist, w, h, channels, null)   (tq.zig:37) ==
+   Host buffers in, one double out; blocking.  Uploads both frames, runs the pyramid,
+   downloads the score. */
+int ssimu2_score_rgb8(ssimu2_ctx* ctx, const uint8_t* ref, const uint8_t* dist, uint32_t w,
+                      uint32_t h, uint32_t channels, double* out_score);
+
+/* The search scores many `dist` frames against one fixed `ref` (tq.zig:37 passes the same
+   e.rgb on every pass, main.zig:86).  set_reference uploads `ref` once and keeps only
+   device copies (its linear-light pyramid); score_against_reference then uploads and
+   scores one `dist`.  Results are bit-identical to ssimu2_score_rgb8 on the same pair. */
+int ssimu2_set_reference(ssimu2_ctx* ctx, const uint8_t* ref, uint32_t w, uint32_t h);
+int ssimu2_score_against_reference(ssimu2_ctx* ctx, const uint8_t* dist, double* out_score);
+
+/* Device-resident variants: `d_ref` / `d_dist` are device pointers (same RGB8 layout)
+   valid on the ctx's device.  _enqueue only enqueues on the ctx stream and returns;
+   ssimu2_wait blocks until the enqueued score is done and returns it.  Used by the
+   batch driver and bench.py (inputs already in HBM), and for fanning speculative
+   quantizer probes over several ctxs/streams. */
+int ssimu2_score_rgb8_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist,
+                             uint32_t w, uint32_t h, double* out_score);
+int ssimu2_enqueue_rgb8_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist,
+                               uint32_t w, uint32_t h);
+int ssimu2_wait(ssimu2_ctx* ctx, double* out_score);
+
+/* The 108 plane averages behind the last finished score, [scale][18] with
+   18 = 6 SSIM (channel*2 + {L1,L4}) then 12 edge (channel*4 + {art L1, art L4, det L1,
+   det L4}); scales not evaluated (image too small) are zero.  For parity tests. */
+int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_STATS_PER_SCALE],
+                         int* out_num_scales);
+
+/* Timing hook for bench.py: enqueue `iters` back-to-back scores of the same device pair
+   bracketed by HIP events on the ctx stream; returns total device milliseconds. */
+int ssimu2_time_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
+                       uint32_t h, int iters, float* out_ms_total, double* out_score);
+
+/* Roofline hook for bench.py: average device milliseconds of ONE launch of the fused
+   per-scale kernel of scale `scale` (0 = full resolution, the dominant kernel), measured
+   with HIP events on the ctx stream around `iters` back-to-back launches.  Runs one full
+   score first so the pyramid the kernel reads is valid. */
+int ssimu2_time_scale_kernel(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
+                             uint32_t h, int scale, int iters, float* out_ms_avg);
+
+/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v1". */
+const char* ssimu2_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSIMU2_HIP_H_ */

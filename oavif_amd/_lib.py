@@ -1,0 +1,111 @@
+"""ctypes binding of liboavif_hip.so (C ABI: include/ssimu2_hip.h, include/oavif_tq.h).
+
+The product path has no CPU fallback: if the library is missing or fails to load this
+module raises, and every scorer call needs a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboavif_hip.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_UNSUPPORTED = -2
+ERR_OOM = -3
+ERR_HIP = -4
+ERR_NO_REFERENCE = -5
+ERR_NO_DEVICE = -6
+
+NUM_SCALES = 6
+STATS_PER_SCALE = 18
+TQ_MAX_PASS = 12
+
+# every symbol the headers declare; tests/test_abi.py checks the .so exports all of them
+EXPORTED_SYMBOLS = (
+    "ssimu2_ctx_create", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
+    "ssimu2_set_reference", "ssimu2_score_against_reference", "ssimu2_score_rgb8_device",
+    "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_time_device",
+    "ssimu2_time_scale_kernel",
+    "ssimu2_version",
+    "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
+    "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
+)
+
+
+class TQOptions(ctypes.Structure):
+    _fields_ = [("score_tgt", ctypes.c_double), ("tolerance", ctypes.c_double),
+                ("max_pass", ctypes.c_uint32)]
+
+
+class TQPass(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_uint32), ("score", ctypes.c_double)]
+
+
+class TQResult(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_uint32), ("score", ctypes.c_double),
+                ("num_pass", ctypes.c_uint32), ("buf_q", ctypes.c_int32),
+                ("history_len", ctypes.c_uint32), ("history", TQPass * TQ_MAX_PASS)]
+
+
+PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                            ctypes.POINTER(ctypes.c_double))
+CODEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                            ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_size_t))
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m oavif_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the scorer.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p, f64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_double)
+    u32, ci = ctypes.c_uint32, ctypes.c_int
+    L.ssimu2_ctx_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
+    L.ssimu2_ctx_create.restype = ci
+    L.ssimu2_ctx_destroy.argtypes = [vp]
+    L.ssimu2_ctx_destroy.restype = None
+    L.ssimu2_last_error.argtypes = [vp]
+    L.ssimu2_last_error.restype = ctypes.c_char_p
+    L.ssimu2_score_rgb8.argtypes = [vp, u8p, u8p, u32, u32, u32, f64p]
+    L.ssimu2_score_rgb8.restype = ci
+    L.ssimu2_set_reference.argtypes = [vp, u8p, u32, u32]
+    L.ssimu2_set_reference.restype = ci
+    L.ssimu2_score_against_reference.argtypes = [vp, u8p, f64p]
+    L.ssimu2_score_against_reference.restype = ci
+    L.ssimu2_score_rgb8_device.argtypes = [vp, vp, vp, u32, u32, f64p]
+    L.ssimu2_score_rgb8_device.restype = ci
+    L.ssimu2_enqueue_rgb8_device.argtypes = [vp, vp, vp, u32, u32]
+    L.ssimu2_enqueue_rgb8_device.restype = ci
+    L.ssimu2_wait.argtypes = [vp, f64p]
+    L.ssimu2_wait.restype = ci
+    L.ssimu2_last_averages.argtypes = [vp, f64p, ctypes.POINTER(ci)]
+    L.ssimu2_last_averages.restype = ci
+    L.ssimu2_time_device.argtypes = [vp, vp, vp, u32, u32, ci, ctypes.POINTER(ctypes.c_float), f64p]
+    L.ssimu2_time_device.restype = ci
+    L.ssimu2_time_scale_kernel.argtypes = [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)]
+    L.ssimu2_time_scale_kernel.restype = ci
+    L.ssimu2_version.argtypes = []
+    L.ssimu2_version.restype = ctypes.c_char_p
+    L.oavif_tq_default_options.argtypes = [ctypes.POINTER(TQOptions)]
+    L.oavif_tq_default_options.restype = None
+    L.oavif_tq_predict_q_from_score.argtypes = [ctypes.c_double]
+    L.oavif_tq_predict_q_from_score.restype = u32
+    L.oavif_tq_interpolate_quantizer.argtypes = [u32, u32, ctypes.POINTER(TQPass), u32, ctypes.c_double]
+    L.oavif_tq_interpolate_quantizer.restype = u32
+    L.oavif_tq_find_target_quality.argtypes = [ctypes.POINTER(TQOptions), PROBE_FN, vp,
+                                               ctypes.POINTER(TQResult)]
+    L.oavif_tq_find_target_quality.restype = ci
+    L.oavif_tq_search_hip.argtypes = [ctypes.POINTER(TQOptions), vp, u8p, u32, u32, CODEC_FN, vp,
+                                      ctypes.POINTER(TQResult), ctypes.POINTER(ctypes.c_size_t)]
+    L.oavif_tq_search_hip.restype = ci
+    _lib = L
+    return L

@@ -1,0 +1,155 @@
+"""Host-side mirror of the scorer interface the reference binds at tq.zig:37.
+
+    fssimu2.computeSsimu2(allocator, ref, dist, w, h, 3, null) -> f64      (tq.zig:37)
+
+`Ssimu2.compute_ssimu2(ref, dist)` is that call on the MI355X; errors surface as
+`Ssimu2Error` carrying the C ABI's negative code (the Zig error-union counterpart).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class Ssimu2Error(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ssimu2 error {code}: {msg}")
+        self.code = code
+
+
+def _u8p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _check_rgb8(a, name: str) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"{name} must be (h, w, 3) uint8, got {a.shape}")
+    return a
+
+
+class Ssimu2:
+    """One scorer context = one HIP stream + device scratch (not re-entrant)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._L = _lib.lib()
+        self._ctx = ctypes.c_void_p()
+        rc = self._L.ssimu2_ctx_create(int(device), ctypes.c_void_p(stream or 0),
+                                       ctypes.byref(self._ctx))
+        if rc != 0:
+            msg = self._L.ssimu2_last_error(None).decode()
+            self._ctx = ctypes.c_void_p()
+            raise Ssimu2Error(rc, msg or "ssimu2_ctx_create failed")
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.ssimu2_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _raise(self, rc: int):
+        raise Ssimu2Error(rc, self._L.ssimu2_last_error(self._ctx).decode())
+
+    # -- host-buffer entry points ---------------------------------------------------------
+    def compute_ssimu2(self, ref, dist, channels: int = 3) -> float:
+        ref = _check_rgb8(ref, "ref")
+        dist = _check_rgb8(dist, "dist")
+        if ref.shape != dist.shape:
+            raise ValueError("ref and dist must have the same shape")
+        h, w, _ = ref.shape
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_score_rgb8(self._ctx, _u8p(ref), _u8p(dist), w, h, channels,
+                                       ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
+    def set_reference(self, ref) -> None:
+        ref = _check_rgb8(ref, "ref")
+        h, w, _ = ref.shape
+        rc = self._L.ssimu2_set_reference(self._ctx, _u8p(ref), w, h)
+        if rc != 0:
+            self._raise(rc)
+        self._ref_shape = ref.shape
+
+    def score_against_reference(self, dist) -> float:
+        dist = _check_rgb8(dist, "dist")
+        if getattr(self, "_ref_shape", None) is not None and dist.shape != self._ref_shape:
+            raise ValueError("dist shape differs from the reference's")
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_score_against_reference(self._ctx, _u8p(dist), ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
+    # -- device-resident entry points (pointers are raw device addresses) -------------------
+    def score_device(self, d_ref: int, d_dist: int, w: int, h: int) -> float:
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_score_rgb8_device(self._ctx, ctypes.c_void_p(d_ref),
+                                              ctypes.c_void_p(d_dist), w, h, ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
+    def enqueue_device(self, d_ref: int, d_dist: int, w: int, h: int) -> None:
+        rc = self._L.ssimu2_enqueue_rgb8_device(self._ctx, ctypes.c_void_p(d_ref),
+                                                ctypes.c_void_p(d_dist), w, h)
+        if rc != 0:
+            self._raise(rc)
+
+    def wait(self) -> float:
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_wait(self._ctx, ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
+    def time_device(self, d_ref: int, d_dist: int, w: int, h: int, iters: int):
+        """-> (total device ms for `iters` back-to-back scores, score)."""
+        ms = ctypes.c_float()
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_time_device(self._ctx, ctypes.c_void_p(d_ref), ctypes.c_void_p(d_dist),
+                                        w, h, iters, ctypes.byref(ms), ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return ms.value, out.value
+
+    def time_scale_kernel(self, d_ref: int, d_dist: int, w: int, h: int, scale: int, iters: int) -> float:
+        """-> average device ms of one launch of the fused kernel of `scale`."""
+        ms = ctypes.c_float()
+        rc = self._L.ssimu2_time_scale_kernel(self._ctx, ctypes.c_void_p(d_ref),
+                                              ctypes.c_void_p(d_dist), w, h, scale, iters,
+                                              ctypes.byref(ms))
+        if rc != 0:
+            self._raise(rc)
+        return ms.value
+
+    def last_averages(self):
+        """-> ((6, 18) float64 plane averages of the last score, number of scales)."""
+        avg = np.zeros(_lib.NUM_SCALES * _lib.STATS_PER_SCALE, np.float64)
+        ns = ctypes.c_int()
+        rc = self._L.ssimu2_last_averages(self._ctx,
+                                          avg.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                          ctypes.byref(ns))
+        if rc != 0:
+            self._raise(rc)
+        return avg.reshape(_lib.NUM_SCALES, _lib.STATS_PER_SCALE), ns.value
+
+
+def version() -> str:
+    return _lib.lib().ssimu2_version().decode()

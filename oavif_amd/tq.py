@@ -1,0 +1,112 @@
+"""Host-side mirror of /root/reference/src/tq.zig over the C ABI (include/oavif_tq.h).
+
+`find_target_quality` is `tq.findTargetQuality` (tq.zig:124-210) with the pass
+(`computeScoreAtQuality`, tq.zig:21-38) injected as `probe(q) -> score`;
+`search_hip` binds the scorer half of each pass to the MI355X scorer and takes the CPU
+codec (encode at q -> decode -> RGB8) as a callback.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+from . import _lib
+from .scorer import Ssimu2, Ssimu2Error
+
+
+@dataclass
+class TQResult:
+    q: int = 0
+    score: float = 0.0
+    num_pass: int = 0
+    buf_q: int = -1
+    history: List[Tuple[int, float]] = field(default_factory=list)
+    last_avif_size: int = 0
+
+
+def _options(score_tgt: float, tolerance: float, max_pass: int) -> _lib.TQOptions:
+    return _lib.TQOptions(float(score_tgt), float(tolerance), int(max_pass))
+
+
+def _result(r: _lib.TQResult) -> TQResult:
+    return TQResult(q=int(r.q), score=float(r.score), num_pass=int(r.num_pass), buf_q=int(r.buf_q),
+                    history=[(int(r.history[i].q), float(r.history[i].score))
+                             for i in range(r.history_len)])
+
+
+def predict_q_from_score(tgt: float) -> int:
+    return int(_lib.lib().oavif_tq_predict_q_from_score(float(tgt)))
+
+
+def interpolate_quantizer(lo: int, hi: int, history, target: float) -> int:
+    n = len(history)
+    arr = (_lib.TQPass * max(n, 1))()
+    for i, (q, s) in enumerate(history):
+        arr[i].q, arr[i].score = int(q), float(s)
+    return int(_lib.lib().oavif_tq_interpolate_quantizer(lo, hi, arr, n, float(target)))
+
+
+def find_target_quality(probe: Callable[[int], float], score_tgt: float = 80.0,
+                        tolerance: float = 2.0, max_pass: int = 6) -> TQResult:
+    L = _lib.lib()
+    err: list = []
+
+    def _cb(_user, q, out):
+        try:
+            out[0] = float(probe(int(q)))
+            return 0
+        except Exception as e:  # surfaces like the Zig `try` at tq.zig:150
+            err.append(e)
+            return -100
+
+    cb = _lib.PROBE_FN(_cb)
+    res = _lib.TQResult()
+    opts = _options(score_tgt, tolerance, max_pass)
+    rc = L.oavif_tq_find_target_quality(ctypes.byref(opts), cb, None, ctypes.byref(res))
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise Ssimu2Error(rc, "oavif_tq_find_target_quality failed")
+    return _result(res)
+
+
+def search_hip(scorer: Ssimu2, ref_rgb: np.ndarray,
+               codec: Callable[[int], Tuple[np.ndarray, int]], score_tgt: float = 80.0,
+               tolerance: float = 2.0, max_pass: int = 6) -> TQResult:
+    """codec(q) -> (decoded (h, w, 3) uint8, avif size in bytes): the CPU encode+decode."""
+    L = _lib.lib()
+    ref = np.ascontiguousarray(ref_rgb, dtype=np.uint8)
+    h, w, _ = ref.shape
+    nbytes = w * h * 3
+    err: list = []
+
+    def _cb(_user, q, out_rgb, out_size):
+        try:
+            dec, size = codec(int(q))
+            dec = np.ascontiguousarray(dec, dtype=np.uint8)
+            if dec.shape != ref.shape:
+                raise ValueError(f"codec returned {dec.shape}, expected {ref.shape}")
+            ctypes.memmove(out_rgb, dec.ctypes.data, nbytes)
+            out_size[0] = int(size)
+            return 0
+        except Exception as e:
+            err.append(e)
+            return -100
+
+    cb = _lib.CODEC_FN(_cb)
+    res = _lib.TQResult()
+    last = ctypes.c_size_t()
+    opts = _options(score_tgt, tolerance, max_pass)
+    rc = L.oavif_tq_search_hip(ctypes.byref(opts), scorer._ctx,
+                               ref.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), w, h, cb, None,
+                               ctypes.byref(res), ctypes.byref(last))
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise Ssimu2Error(rc, L.ssimu2_last_error(scorer._ctx).decode())
+    out = _result(res)
+    out.last_avif_size = int(last.value)
+    return out

@@ -1,0 +1,464 @@
+/*
+ * oracle/ssimu2_oracle.c -- CPU restatement of the SSIMULACRA2 score that oavif's
+ * target-quality search computes once per pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oavif_amd/ (the product) may link, load or
+ * call this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it, and only as the checker / the timed CPU baseline.
+ *
+ * What it restates
+ * ----------------
+ * The reference calls the scorer at exactly one place:
+ *     /root/reference/src/tq.zig:37
+ *         return try fssimu2.computeSsimu2(allocator, e.rgb, decoded_rgb, e.w, e.h, 3, null);
+ * `fssimu2` is a third-party Zig package pinned by URL + hash at
+ * /root/reference/build.zig.zon:7-10 (tag 0.1.1).  Its source is NOT in /root/reference
+ * and NOT on this machine (no vendored copy, no package cache, no network), and the
+ * reference has no tests, golden vectors or fixtures for this path.
+ *
+ *     ==> PARITY UNPINNED against fssimu2 0.1.1. <==
+ *
+ * What is restated instead is the *published* SSIMULACRA2 v2.1 algorithm (libjxl
+ * tools/ssimulacra2.cc + lib/jxl/gauss_blur.cc + lib/jxl/enc_xyb.cc), written from the
+ * public description of that algorithm, which is the algorithm BASELINE.json's
+ * north_star lists stage by stage (sRGB->linear->XYB, 6-scale 2x downsample, separable
+ * Gaussian blur, SSIM + edge-difference maps, 108-weight reduction).  Input contract is
+ * the reference's own: two tightly packed 8-bit interleaved RGB buffers of w*h*3 bytes
+ * (/root/reference/src/main.zig:86, /root/reference/src/io.zig:647-663).
+ *
+ * Two blur formulations, selectable per call, proven equivalent in exact arithmetic by
+ * tests/test_oracle.py:
+ *   OR_BLUR_IIR (0)  libjxl's recursive Gaussian (Charalampidis 2016, sigma 1.5, three
+ *                    undamped 2nd-order sections fed by in[n-N-1]+in[n+N-1], N=5, zero
+ *                    outside the image), fp32 state, horizontal pass then vertical.
+ *   OR_BLUR_FIR (1)  the same operator written as what it is in exact arithmetic: a
+ *                    symmetric 9-tap FIR (taps -4..4) with zero padding, fp32.
+ * The fp32 recursion is NOT numerically equivalent: its sections are undamped, so
+ * rounding error random-walks along every row and column (measured rms 7e-7 vs 1.4e-8
+ * for the FIR on a 512x512 plane) and, through the max(0, .) in the maps, biases scores
+ * by ~0.01-0.1 points near 80 and up to ~1.4 points near 95.  That noise is a property
+ * of one fp32 evaluation order (libjxl's own SIMD targets differ from each other in it),
+ * not of the algorithm, so the FIR form is the oracle's PRIMARY mode and the one the HIP
+ * path implements (LDS rows with halo) and is compared with; the IIR mode is kept to
+ * quantify the gap (tests/test_oracle.py, DESIGN.md "Oracle").
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; -fopenmp variant for timing).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define OR_NUM_SCALES 6
+#define OR_BLUR_IIR 0
+#define OR_BLUR_FIR 1
+
+/* ---- constants of the published algorithm ------------------------------------- */
+
+static const float kC2 = 0.0009f;
+
+/* opsin absorbance (libjxl opsin_params.h), rows L, M, S */
+static const float kM00 = 0.30f, kM01 = 0.622f, kM02 = 0.078f;
+static const float kM10 = 0.23f, kM11 = 0.692f, kM12 = 0.078f;
+static const float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
+                   kM22 = 0.55180986650955360f; /* 1 - kM20 - kM21 */
+static const float kOpsinBias = 0.0037930732552754493f;
+
+/* 108 trained weights; for a six-scale image index = ((channel*6 + scale)*2 + norm)*3 +
+   {ssim, artifact, detail_lost} (see or_score_from_averages for the running index). */
+static const double kWeights[108] = {
+    0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0,
+    0.0, 0.0004371155730107379, 0.0, 1.1041726426657346, 0.00066284834129271,
+    0.00015231632783718752, 0.0, 0.0016406437456599754, 0.0, 1.8422455520539298,
+    11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0,
+    1.8787594979546387, 10.949069906051982, 0.0, 0.0007289346991508072,
+    0.9677937080626833, 0.0, 0.00014003424285435884, 0.9981766977854967,
+    0.00031949755934435053, 0.0004550992113792063, 0.0, 0.0, 0.0013648766163243398,
+    0.0, 0.0, 0.0, 0.0, 0.0, 7.466890328078848, 0.0, 17.445833984131262,
+    0.0006235601634041466, 0.0, 0.0, 6.683678146179332, 0.00037724407979611296,
+    1.027889937768264, 225.20515300849274, 0.0, 0.0, 19.213238186143016,
+    0.0011401524586618361, 0.001237755635509985, 176.39317598450694, 0.0, 0.0,
+    24.43300999870476, 0.28520802612117757, 0.0004485436923833408, 0.0, 0.0, 0.0,
+    34.77906344483772, 44.835625328877896, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+    0.0008680556573291698, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0005313191874358747, 0.0,
+    0.00016533814161379112, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0004179171803251336,
+    0.0017290828234722833, 0.0, 0.0020827005846636437, 0.0, 0.0, 8.826982764996862,
+    23.19243343998926, 0.0, 95.1080498811086, 0.9863978034400682, 0.9834382792465353,
+    0.0012286405048278493, 171.2667255897307, 0.9807858872435379, 0.0, 0.0, 0.0,
+    0.0005130064588990679, 0.0, 0.00010854057858411537};
+
+/* ---- recursive Gaussian coefficients (Charalampidis 2016; libjxl gauss_blur.cc) -- */
+
+typedef struct {
+    int radius;      /* N = 5 for sigma 1.5 */
+    float n2[3];     /* input gains of the three sections */
+    float d1[3];     /* -2 cos(omega_k) */
+    double n2d[3], d1d[3];
+    float fir[5];    /* equivalent FIR taps |d| = 0..4 (fp32 of the exact value) */
+    double fird[5];
+} or_gauss;
+
+static void inv3x3(double m[9]) {
+    double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7],
+           i = m[8];
+    double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    double det = a * A + b * B + c * C;
+    double r[9] = {A, -(b * i - c * h), b * f - c * e,
+                   B, a * i - c * g, -(a * f - c * d),
+                   C, -(a * h - b * g), a * e - b * d};
+    for (int k = 0; k < 9; ++k) m[k] = r[k] / det;
+}
+
+void or_gauss_create(double sigma, or_gauss* rg) {
+    const double kPi = 3.141592653589793238;
+    const double radius = round(3.2795 * sigma + 0.2546);
+    const double pi_div_2r = kPi / (2.0 * radius);
+    const double omega[3] = {pi_div_2r, 3.0 * pi_div_2r, 5.0 * pi_div_2r};
+    const double p_1 = +1.0 / tan(0.5 * omega[0]);
+    const double p_3 = -1.0 / tan(0.5 * omega[1]);
+    const double p_5 = +1.0 / tan(0.5 * omega[2]);
+    const double r_1 = +p_1 * p_1 / sin(omega[0]);
+    const double r_3 = -p_3 * p_3 / sin(omega[1]);
+    const double r_5 = +p_5 * p_5 / sin(omega[2]);
+    const double neg_half_sigma2 = -0.5 * sigma * sigma;
+    double rho[3];
+    for (int i = 0; i < 3; ++i) rho[i] = exp(neg_half_sigma2 * omega[i] * omega[i]) / radius;
+    const double D_13 = p_1 * r_3 - r_1 * p_3;
+    const double D_35 = p_3 * r_5 - r_3 * p_5;
+    const double D_51 = p_5 * r_1 - r_5 * p_1;
+    const double zeta_15 = D_35 / D_13;
+    const double zeta_35 = D_51 / D_13;
+    double A[9] = {p_1, p_3, p_5, r_1, r_3, r_5, zeta_15, zeta_35, 1.0};
+    inv3x3(A);
+    const double gamma[3] = {1.0, radius * radius - sigma * sigma,
+                             zeta_15 * rho[0] + zeta_35 * rho[1] + rho[2]};
+    double beta[3];
+    for (int i = 0; i < 3; ++i)
+        beta[i] = A[3 * i] * gamma[0] + A[3 * i + 1] * gamma[1] + A[3 * i + 2] * gamma[2];
+    rg->radius = (int)radius;
+    for (int i = 0; i < 3; ++i) {
+        rg->n2d[i] = -beta[i] * cos(omega[i] * (radius + 1.0));
+        rg->d1d[i] = -2.0 * cos(omega[i]);
+        rg->n2[i] = (float)rg->n2d[i];
+        rg->d1[i] = (float)rg->d1d[i];
+    }
+    /* Impulse response of the three sections driven by in[n-N-1]+in[n+N-1]:
+       w(d) = sum_k n2_k/sin(w_k) * sin(w_k (d+N)), d in [-N+1, N-1]; zero elsewhere. */
+    for (int d = 0; d < 5; ++d) {
+        double w = 0.0;
+        for (int k = 0; k < 3; ++k)
+            w += rg->n2d[k] / sin(omega[k]) * sin(omega[k] * (d + radius));
+        rg->fird[d] = w;
+        rg->fir[d] = (float)w;
+    }
+}
+
+/* exported for tests: taps as fp64 and fp32 */
+void or_gauss_taps(double* taps5_f64, float* taps5_f32, double* n2_3, double* d1_3) {
+    or_gauss rg;
+    or_gauss_create(1.5, &rg);
+    for (int i = 0; i < 5; ++i) {
+        taps5_f64[i] = rg.fird[i];
+        taps5_f32[i] = rg.fir[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        n2_3[i] = rg.n2d[i];
+        d1_3[i] = rg.d1d[i];
+    }
+}
+
+/* 1-D recursive pass over a strided line (scalar form of libjxl FastGaussian1D). */
+static void iir_line(const or_gauss* rg, const float* in, ptrdiff_t n_in, ptrdiff_t stride_in,
+                     float* out, ptrdiff_t stride_out) {
+    const ptrdiff_t N = rg->radius;
+    const float n2_1 = rg->n2[0], n2_3 = rg->n2[1], n2_5 = rg->n2[2];
+    const float d1_1 = rg->d1[0], d1_3 = rg->d1[1], d1_5 = rg->d1[2];
+    float prev_1 = 0, prev_3 = 0, prev_5 = 0, prev2_1 = 0, prev2_3 = 0, prev2_5 = 0;
+    for (ptrdiff_t n = -N + 1; n < n_in; ++n) {
+        const ptrdiff_t left = n - N - 1, right = n + N - 1;
+        const float lv = left >= 0 ? in[left * stride_in] : 0.0f;
+        const float rv = right < n_in ? in[right * stride_in] : 0.0f;
+        const float sum = lv + rv;
+        float o1 = sum * n2_1, o3 = sum * n2_3, o5 = sum * n2_5;
+        o1 = o1 - prev2_1;
+        o3 = o3 - prev2_3;
+        o5 = o5 - prev2_5;
+        o1 = o1 - d1_1 * prev_1;
+        o3 = o3 - d1_3 * prev_3;
+        o5 = o5 - d1_5 * prev_5;
+        prev2_1 = prev_1; prev2_3 = prev_3; prev2_5 = prev_5;
+        prev_1 = o1; prev_3 = o3; prev_5 = o5;
+        if (n >= 0) out[n * stride_out] = o1 + o3 + o5;
+    }
+}
+
+static void fir_line(const or_gauss* rg, const float* in, ptrdiff_t n_in, ptrdiff_t stride_in,
+                     float* out, ptrdiff_t stride_out) {
+    const float w0 = rg->fir[0], w1 = rg->fir[1], w2 = rg->fir[2], w3 = rg->fir[3],
+                w4 = rg->fir[4];
+#define AT(i) (((i) >= 0 && (i) < n_in) ? in[(i) * stride_in] : 0.0f)
+    /* Operation order is part of the contract with the HIP kernels (they evaluate the
+       same mul + four fused multiply-adds), so the two blurs agree bit for bit. */
+    for (ptrdiff_t n = 0; n < n_in; ++n) {
+        float acc = w0 * AT(n);
+        acc = fmaf(w1, AT(n - 1) + AT(n + 1), acc);
+        acc = fmaf(w2, AT(n - 2) + AT(n + 2), acc);
+        acc = fmaf(w3, AT(n - 3) + AT(n + 3), acc);
+        acc = fmaf(w4, AT(n - 4) + AT(n + 4), acc);
+        out[n * stride_out] = acc;
+    }
+#undef AT
+}
+
+/* 2-D blur of one w*h plane: horizontal into tmp, vertical into out. */
+static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, size_t h,
+                       float* tmp, float* out) {
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t y = 0; y < (ptrdiff_t)h; ++y) {
+        if (mode == OR_BLUR_IIR) iir_line(rg, in + y * w, w, 1, tmp + y * w, 1);
+        else fir_line(rg, in + y * w, w, 1, tmp + y * w, 1);
+    }
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t x = 0; x < (ptrdiff_t)w; ++x) {
+        if (mode == OR_BLUR_IIR) iir_line(rg, tmp + x, h, w, out + x, w);
+        else fir_line(rg, tmp + x, h, w, out + x, w);
+    }
+}
+
+/* exported for tests: blur one plane */
+void or_blur_plane(const float* in, uint32_t w, uint32_t h, int mode, float* out) {
+    or_gauss rg;
+    or_gauss_create(1.5, &rg);
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)w * h);
+    blur_plane(&rg, mode, in, w, h, tmp, out);
+    free(tmp);
+}
+
+/* ---- colour: 8-bit sRGB -> linear -> XYB ------------------------------------------ */
+
+void or_srgb_lut(float* lut256) {
+    for (int i = 0; i < 256; ++i) {
+        double v = (double)i / 255.0;
+        double l = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4);
+        lut256[i] = (float)l;
+    }
+}
+
+/* interleaved RGB8 -> three linear planes */
+static void rgb8_to_linear(const uint8_t* rgb, size_t n, float* lin /* 3*n */) {
+    float lut[256];
+    or_srgb_lut(lut);
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
+        lin[i] = lut[rgb[3 * i]];
+        lin[n + i] = lut[rgb[3 * i + 1]];
+        lin[2 * n + i] = lut[rgb[3 * i + 2]];
+    }
+}
+
+/* linear RGB planes -> "positive XYB" planes (ToXYB then MakePositiveXYB) */
+void or_linear_to_xyb(const float* lin, size_t n, float* xyb) {
+    const float cb = cbrtf(kOpsinBias);
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
+        const float r = lin[i], g = lin[n + i], b = lin[2 * n + i];
+        float l = kM00 * r + kM01 * g + kM02 * b + kOpsinBias;
+        float m = kM10 * r + kM11 * g + kM12 * b + kOpsinBias;
+        float s = kM20 * r + kM21 * g + kM22 * b + kOpsinBias;
+        l = l < 0.0f ? 0.0f : l;
+        m = m < 0.0f ? 0.0f : m;
+        s = s < 0.0f ? 0.0f : s;
+        l = cbrtf(l) - cb;
+        m = cbrtf(m) - cb;
+        s = cbrtf(s) - cb;
+        const float X = 0.5f * (l - m), Y = 0.5f * (l + m), B = s;
+        xyb[2 * n + i] = (B - Y) + 0.55f;
+        xyb[i] = X * 14.0f + 0.42f;
+        xyb[n + i] = Y + 0.01f;
+    }
+}
+
+/* 2x2 box average of linear planes, edge pixels replicated (Downsample(in,2,2)) */
+void or_downsample2(const float* in, size_t w, size_t h, float* out) {
+    const size_t ow = (w + 1) / 2, oh = (h + 1) / 2;
+    for (int c = 0; c < 3; ++c) {
+        const float* pin = in + (size_t)c * w * h;
+        float* pout = out + (size_t)c * ow * oh;
+#pragma omp parallel for schedule(static)
+        for (ptrdiff_t oy = 0; oy < (ptrdiff_t)oh; ++oy) {
+            for (size_t ox = 0; ox < ow; ++ox) {
+                float sum = 0.0f;
+                for (size_t iy = 0; iy < 2; ++iy)
+                    for (size_t ix = 0; ix < 2; ++ix) {
+                        size_t x = ox * 2 + ix, y = (size_t)oy * 2 + iy;
+                        if (x > w - 1) x = w - 1;
+                        if (y > h - 1) y = h - 1;
+                        sum += pin[y * w + x];
+                    }
+                pout[oy * ow + ox] = sum * 0.25f;
+            }
+        }
+    }
+}
+
+/* ---- maps ----------------------------------------------------------------------- */
+
+static double tothe4th(double x) { x *= x; x *= x; return x; }
+
+static void ssim_map(const float* m1, const float* m2, const float* s11, const float* s22,
+                     const float* s12, size_t n, double* plane_avg /* 6 */) {
+    const double one_per_pixels = 1.0 / (double)n;
+    for (int c = 0; c < 3; ++c) {
+        double sum0 = 0.0, sum1 = 0.0;
+        const float *a = m1 + c * n, *b = m2 + c * n, *p11 = s11 + c * n, *p22 = s22 + c * n,
+                    *p12 = s12 + c * n;
+#pragma omp parallel for schedule(static) reduction(+ : sum0, sum1)
+        for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
+            const float mu1 = a[i], mu2 = b[i];
+            const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+            const float num_m = 1.0f - (mu1 - mu2) * (mu1 - mu2);
+            const float num_s = 2.0f * (p12[i] - mu12) + kC2;
+            const float denom_s = (p11[i] - mu11) + (p22[i] - mu22) + kC2;
+            double d = 1.0 - (double)(num_m * num_s / denom_s);
+            d = d > 0.0 ? d : 0.0;
+            sum0 += d;
+            sum1 += tothe4th(d);
+        }
+        plane_avg[c * 2] = one_per_pixels * sum0;
+        plane_avg[c * 2 + 1] = sqrt(sqrt(one_per_pixels * sum1));
+    }
+}
+
+static void edge_diff_map(const float* img1, const float* mu1, const float* img2,
+                          const float* mu2, size_t n, double* plane_avg /* 12 */) {
+    const double one_per_pixels = 1.0 / (double)n;
+    for (int c = 0; c < 3; ++c) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const float *r1 = img1 + c * n, *rm1 = mu1 + c * n, *r2 = img2 + c * n,
+                    *rm2 = mu2 + c * n;
+#pragma omp parallel for schedule(static) reduction(+ : s0, s1, s2, s3)
+        for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
+            const double d1 = (1.0 + fabs((double)(r2[i] - rm2[i]))) /
+                                  (1.0 + fabs((double)(r1[i] - rm1[i]))) -
+                              1.0;
+            const double artifact = d1 > 0.0 ? d1 : 0.0;
+            s0 += artifact;
+            s1 += tothe4th(artifact);
+            const double detail_lost = d1 < 0.0 ? -d1 : 0.0;
+            s2 += detail_lost;
+            s3 += tothe4th(detail_lost);
+        }
+        plane_avg[c * 4] = one_per_pixels * s0;
+        plane_avg[c * 4 + 1] = sqrt(sqrt(one_per_pixels * s1));
+        plane_avg[c * 4 + 2] = one_per_pixels * s2;
+        plane_avg[c * 4 + 3] = sqrt(sqrt(one_per_pixels * s3));
+    }
+}
+
+/* 108 averages -> score.  avg layout: [scale][18] = 6 ssim (c*2+n) then 12 edge (c*4+k). */
+double or_score_from_averages(const double* avg /* nscales*18 */, int nscales) {
+    /* The published Score() walks `for c: for scale < scales.size(): for n` with a
+       running weight index, so an image too small for all six scales consumes the
+       weights contiguously (no gaps for the missing scales).  Kept as published. */
+    double ssim = 0.0;
+    size_t i = 0;
+    for (int c = 0; c < 3; ++c) {
+        for (int scale = 0; scale < nscales; ++scale) {
+            const double* a = avg + scale * 18;
+            for (int n = 0; n < 2; ++n) {
+                ssim += kWeights[i++] * fabs(a[c * 2 + n]);
+                ssim += kWeights[i++] * fabs(a[6 + c * 4 + n]);
+                ssim += kWeights[i++] * fabs(a[6 + c * 4 + n + 2]);
+            }
+        }
+    }
+    ssim = ssim * 0.9562382616834844;
+    ssim = 2.326765642916932 * ssim - 0.020884521182843837 * ssim * ssim +
+           6.248496625763138e-05 * ssim * ssim * ssim;
+    if (ssim > 0.0) ssim = 100.0 - 10.0 * pow(ssim, 0.6276336467831387);
+    else ssim = 100.0;
+    return ssim;
+}
+
+void or_weights(double* out108) { memcpy(out108, kWeights, sizeof(kWeights)); }
+
+/* ---- the entry point: same contract as the call at tq.zig:37 ---------------------- */
+/* returns 0 on success; *out_score is the SSIMULACRA2 score; avg_out (optional) gets
+   6*18 doubles (unused scales zero), nscales_out (optional) the scales evaluated. */
+int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h,
+                      uint32_t channels, int blur_mode, double* out_score, double* avg_out,
+                      int* nscales_out) {
+    if (!ref || !dist || !out_score) return -1;
+    if (channels != 3) return -2;
+    if (w == 0 || h == 0) return -3;
+    or_gauss rg;
+    or_gauss_create(1.5, &rg);
+    size_t n = (size_t)w * h;
+    float* lin1 = (float*)malloc(sizeof(float) * 3 * n);
+    float* lin2 = (float*)malloc(sizeof(float) * 3 * n);
+    float* img1 = (float*)malloc(sizeof(float) * 3 * n);
+    float* img2 = (float*)malloc(sizeof(float) * 3 * n);
+    float* mul = (float*)malloc(sizeof(float) * 3 * n);
+    float* s11 = (float*)malloc(sizeof(float) * 3 * n);
+    float* s22 = (float*)malloc(sizeof(float) * 3 * n);
+    float* s12 = (float*)malloc(sizeof(float) * 3 * n);
+    float* mu1 = (float*)malloc(sizeof(float) * 3 * n);
+    float* mu2 = (float*)malloc(sizeof(float) * 3 * n);
+    float* tmp = (float*)malloc(sizeof(float) * n);
+    float* dtmp = (float*)malloc(sizeof(float) * 3 * ((n + 3) / 4 + w + h + 4));
+    if (!lin1 || !lin2 || !img1 || !img2 || !mul || !s11 || !s22 || !s12 || !mu1 || !mu2 ||
+        !tmp || !dtmp) {
+        free(lin1); free(lin2); free(img1); free(img2); free(mul); free(s11); free(s22);
+        free(s12); free(mu1); free(mu2); free(tmp); free(dtmp);
+        return -4;
+    }
+    rgb8_to_linear(ref, n, lin1);
+    rgb8_to_linear(dist, n, lin2);
+
+    double avg[OR_NUM_SCALES * 18];
+    memset(avg, 0, sizeof(avg));
+    int nscales = 0;
+    size_t cw = w, ch = h;
+    for (int scale = 0; scale < OR_NUM_SCALES; ++scale) {
+        if (cw < 8 || ch < 8) break;
+        if (scale) {
+            const size_t ow = (cw + 1) / 2, oh = (ch + 1) / 2;
+            or_downsample2(lin1, cw, ch, dtmp);
+            memcpy(lin1, dtmp, sizeof(float) * 3 * ow * oh);
+            or_downsample2(lin2, cw, ch, dtmp);
+            memcpy(lin2, dtmp, sizeof(float) * 3 * ow * oh);
+            cw = ow;
+            ch = oh;
+            /* libjxl tests the size BEFORE downsampling for this scale; the downsampled
+               image is scored even if it is now smaller than 8. */
+        }
+        n = cw * ch;
+        or_linear_to_xyb(lin1, n, img1);
+        or_linear_to_xyb(lin2, n, img2);
+        for (int c = 0; c < 3; ++c) {
+            const float *a = img1 + c * n, *b = img2 + c * n;
+            float* m = mul + c * n;
+#pragma omp parallel for schedule(static)
+            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = a[i] * a[i];
+            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s11 + c * n);
+#pragma omp parallel for schedule(static)
+            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = b[i] * b[i];
+            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s22 + c * n);
+#pragma omp parallel for schedule(static)
+            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = a[i] * b[i];
+            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s12 + c * n);
+            blur_plane(&rg, blur_mode, a, cw, ch, tmp, mu1 + c * n);
+            blur_plane(&rg, blur_mode, b, cw, ch, tmp, mu2 + c * n);
+        }
+        ssim_map(mu1, mu2, s11, s22, s12, n, avg + scale * 18);
+        edge_diff_map(img1, mu1, img2, mu2, n, avg + scale * 18 + 6);
+        ++nscales;
+    }
+    *out_score = or_score_from_averages(avg, nscales);
+    if (avg_out) memcpy(avg_out, avg, sizeof(avg));
+    if (nscales_out) *nscales_out = nscales;
+    free(lin1); free(lin2); free(img1); free(img2); free(mul); free(s11); free(s22);
+    free(s12); free(mu1); free(mu2); free(tmp); free(dtmp);
+    return 0;
+}

@@ -1,0 +1,144 @@
+"""ctypes front-end of the CPU oracle (oracle/ssimu2_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of ssimu2_oracle.c.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by oavif_amd/.
+
+Parity status: UNPINNED against fssimu2 0.1.1 (source absent, reference has no tests);
+restates the published SSIMULACRA2 v2.1 algorithm behind the signature seen at
+/root/reference/src/tq.zig:37.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLUR_IIR = 0  # libjxl recursive Gaussian, as published
+BLUR_FIR = 1  # its exact-arithmetic equivalent, 9-tap zero-padded FIR
+
+_libs: dict[bool, ctypes.CDLL] = {}
+
+
+def build() -> None:
+    """Compile the oracle (both the scalar and the OpenMP build)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def _lib(omp: bool = False) -> ctypes.CDLL:
+    if omp not in _libs:
+        name = "libssimu2_oracle_omp.so" if omp else "libssimu2_oracle.so"
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        lib = ctypes.CDLL(path)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        lib.or_compute_ssimu2.argtypes = [u8p, u8p, ctypes.c_uint32, ctypes.c_uint32,
+                                          ctypes.c_uint32, ctypes.c_int, f64p, f64p,
+                                          ctypes.POINTER(ctypes.c_int)]
+        lib.or_compute_ssimu2.restype = ctypes.c_int
+        lib.or_blur_plane.argtypes = [f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, f32p]
+        lib.or_blur_plane.restype = None
+        lib.or_gauss_taps.argtypes = [f64p, f32p, f64p, f64p]
+        lib.or_gauss_taps.restype = None
+        lib.or_srgb_lut.argtypes = [f32p]
+        lib.or_srgb_lut.restype = None
+        lib.or_linear_to_xyb.argtypes = [f32p, ctypes.c_size_t, f32p]
+        lib.or_linear_to_xyb.restype = None
+        lib.or_downsample2.argtypes = [f32p, ctypes.c_size_t, ctypes.c_size_t, f32p]
+        lib.or_downsample2.restype = None
+        lib.or_score_from_averages.argtypes = [f64p, ctypes.c_int]
+        lib.or_score_from_averages.restype = ctypes.c_double
+        lib.or_weights.argtypes = [f64p]
+        lib.or_weights.restype = None
+        _libs[omp] = lib
+    return _libs[omp]
+
+
+def _u8(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _f32(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _f64(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def compute_ssimu2(ref: np.ndarray, dist: np.ndarray, blur: int = BLUR_IIR, omp: bool = False,
+                   return_averages: bool = False):
+    """Score `dist` against `ref`; both (h, w, 3) uint8, tightly packed.
+
+    Mirrors `fssimu2.computeSsimu2(allocator, ref, dist, w, h, 3, null)` (tq.zig:37).
+    """
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    dist = np.ascontiguousarray(dist, dtype=np.uint8)
+    if ref.shape != dist.shape or ref.ndim != 3 or ref.shape[2] != 3:
+        raise ValueError("ref and dist must both be (h, w, 3) uint8")
+    h, w, _ = ref.shape
+    score = ctypes.c_double(0.0)
+    avg = np.zeros(6 * 18, dtype=np.float64)
+    nsc = ctypes.c_int(0)
+    rc = _lib(omp).or_compute_ssimu2(_u8(ref), _u8(dist), w, h, 3, blur, ctypes.byref(score),
+                                     _f64(avg), ctypes.byref(nsc))
+    if rc != 0:
+        raise RuntimeError(f"or_compute_ssimu2 failed rc={rc}")
+    if return_averages:
+        return score.value, avg.reshape(6, 18), nsc.value
+    return score.value
+
+
+def blur_plane(plane: np.ndarray, blur: int = BLUR_IIR) -> np.ndarray:
+    plane = np.ascontiguousarray(plane, dtype=np.float32)
+    h, w = plane.shape
+    out = np.empty_like(plane)
+    _lib().or_blur_plane(_f32(plane), w, h, blur, _f32(out))
+    return out
+
+
+def gauss_taps():
+    t64 = np.zeros(5, np.float64)
+    t32 = np.zeros(5, np.float32)
+    n2 = np.zeros(3, np.float64)
+    d1 = np.zeros(3, np.float64)
+    _lib().or_gauss_taps(_f64(t64), _f32(t32), _f64(n2), _f64(d1))
+    return t64, t32, n2, d1
+
+
+def srgb_lut() -> np.ndarray:
+    lut = np.zeros(256, np.float32)
+    _lib().or_srgb_lut(_f32(lut))
+    return lut
+
+
+def linear_to_xyb(lin: np.ndarray) -> np.ndarray:
+    """lin: (3, h, w) float32 linear RGB planes -> (3, h, w) positive-XYB planes."""
+    lin = np.ascontiguousarray(lin, dtype=np.float32)
+    out = np.empty_like(lin)
+    _lib().or_linear_to_xyb(_f32(lin), lin.shape[1] * lin.shape[2], _f32(out))
+    return out
+
+
+def downsample2(lin: np.ndarray) -> np.ndarray:
+    lin = np.ascontiguousarray(lin, dtype=np.float32)
+    _, h, w = lin.shape
+    out = np.empty((3, (h + 1) // 2, (w + 1) // 2), np.float32)
+    _lib().or_downsample2(_f32(lin), w, h, _f32(out))
+    return out
+
+
+def score_from_averages(avg: np.ndarray, nscales: int) -> float:
+    avg = np.ascontiguousarray(avg, dtype=np.float64).reshape(-1)
+    return float(_lib().or_score_from_averages(_f64(avg), nscales))
+
+
+def weights() -> np.ndarray:
+    w = np.zeros(108, np.float64)
+    _lib().or_weights(_f64(w))
+    return w

@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports every symbol the headers declare."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b((?:ssimu2|oavif_tq)_[a-z0-9_]+)\s*\(", text)
+    # drop typedef'd function-pointer types
+    return sorted({n for n in names if not n.endswith("_fn")})
+
+
+def test_headers_and_binding_agree(hip_lib):
+    from oavif_amd import _lib
+    declared = set(_declared_functions("ssimu2_hip.h")) | set(_declared_functions("oavif_tq.h"))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for header in ("ssimu2_hip.h", "oavif_tq.h"):
+        for name in _declared_functions(header):
+            assert hasattr(hip_lib, name), f"{name} declared in {header} but not exported"
+
+
+def test_version_string(hip_lib):
+    assert b"gfx950" in hip_lib.ssimu2_version()
+
+
+def test_null_and_bad_arguments_return_codes(hip_lib):
+    from oavif_amd import _lib
+    assert hip_lib.ssimu2_ctx_create(0, None, None) == _lib.ERR_INVALID_ARG
+    assert hip_lib.ssimu2_wait(None, None) == _lib.ERR_INVALID_ARG
+    assert hip_lib.ssimu2_set_reference(None, None, 1, 1) == _lib.ERR_INVALID_ARG
+    out = ctypes.c_double()
+    assert hip_lib.ssimu2_score_against_reference(None, None, ctypes.byref(out)) == _lib.ERR_INVALID_ARG
+    hip_lib.ssimu2_ctx_destroy(None)  # must be a no-op
+    res = _lib.TQResult()
+    assert hip_lib.oavif_tq_find_target_quality(None, _lib.PROBE_FN(lambda u, q, o: 0), None,
+                                                ctypes.byref(res)) == _lib.ERR_INVALID_ARG
+
+
+def test_no_cpu_fallback_without_device(hip_lib):
+    """Without a GPU the scorer must refuse loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from oavif_amd import Ssimu2, Ssimu2Error, _lib
+    with pytest.raises(Ssimu2Error) as ei:
+        Ssimu2(0)
+    assert ei.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under oavif_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "oavif_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".zig")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "ssimu2_oracle" not in text and "tq_oracle" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

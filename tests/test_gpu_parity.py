@@ -1,0 +1,194 @@
+"""Parity of the HIP scorer (through the C ABI) with the CPU oracle.  -m gpu only.
+
+Tolerances (written here, as the task requires):
+  * vs the oracle's primary (FIR) mode: |dscore| <= 2e-4 and the 108 plane averages to
+    rtol 2e-5 -- the blur is bit-identical by construction, what remains is cbrt / division
+    / reduction-order rounding.  North_star's bar is +-0.01.
+  * vs the oracle's published-recursion (IIR, fp32) mode: not asserted to +-0.01; the gap is
+    that recursion's own rounding noise (tests/test_oracle.py, DESIGN.md "Oracle").
+The reference has no vectors for this path and its scorer source is absent: every
+"expected" here is the repo's own oracle -- fssimu2 parity is UNPINNED.
+"""
+import numpy as np
+import pytest
+
+from oavif_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCORE = 2e-4
+RTOL_AVG = 2e-5
+
+
+def _check_pair(scorer, oracle, ref, dist, tol=TOL_SCORE):
+    got = scorer.compute_ssimu2(ref, dist)
+    avg_g, ns_g = scorer.last_averages()
+    exp, avg_o, ns_o = oracle.compute_ssimu2(ref, dist, oracle.BLUR_FIR, return_averages=True)
+    assert ns_g == ns_o
+    assert np.allclose(avg_g, avg_o, rtol=RTOL_AVG, atol=1e-9), \
+        np.abs(avg_g - avg_o).max()
+    assert abs(got - exp) <= tol, (got, exp)
+    return got, exp
+
+
+def test_golden_fixtures(scorer, oracle, golden):
+    arrays, meta = golden
+    ref = arrays["ref"]
+    for p in meta["pairs"]:
+        got = scorer.compute_ssimu2(ref, arrays[p["name"]])
+        avg, ns = scorer.last_averages()
+        assert ns == 6
+        assert abs(got - p["score_fir"]) <= TOL_SCORE, (p["name"], got, p["score_fir"])
+        assert np.allclose(avg.reshape(-1), p["averages_fir"], rtol=RTOL_AVG, atol=1e-9), p["name"]
+    o = meta["odd"]
+    got = scorer.compute_ssimu2(arrays["odd_ref"], arrays["odd_dist"])
+    assert abs(got - o["score_fir"]) <= TOL_SCORE
+
+
+def test_identical_is_exactly_100(scorer):
+    ref = synth.make_ref(300, 200, 11)
+    assert scorer.compute_ssimu2(ref, ref) == 100.0
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (9, 15), (16, 16), (31, 33), (32, 32), (33, 31),
+                                 (64, 40), (65, 41), (100, 7), (7, 100), (1, 1), (127, 129),
+                                 (255, 3), (513, 259)])
+def test_ragged_and_tiny_sizes(scorer, oracle, w, h):
+    ref = synth.make_ref(w, h, w * 1000 + h)
+    dist = synth.distort(ref, "noise", 2, seed=w)
+    _check_pair(scorer, oracle, ref, dist)
+
+
+@pytest.mark.parametrize("kind,strength", [("blockq", 0), ("blockq", 4), ("noise", 0), ("noise", 4),
+                                           ("blur", 2), ("band", 1), ("band", 4)])
+def test_distortion_ladder_512(scorer, oracle, kind, strength):
+    ref = synth.make_ref(512, 512, 21)
+    dist = synth.distort(ref, kind, strength, seed=5)
+    _check_pair(scorer, oracle, ref, dist)
+
+
+def test_extreme_frames(scorer, oracle):
+    h, w = 70, 90
+    black = np.zeros((h, w, 3), np.uint8)
+    white = np.full((h, w, 3), 255, np.uint8)
+    rng = np.random.default_rng(0)
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    for a, b in [(black, white), (white, black), (noise, black), (black, noise),
+                 (noise, noise[::-1].copy())]:
+        _check_pair(scorer, oracle, a, b, tol=5e-4)   # scores far below 0 here
+
+
+def test_1080p_pair(scorer, oracle):
+    ref = synth.make_ref(1920, 1080, 31)
+    dist = synth.distort(ref, "blockq", 1)
+    _check_pair(scorer, oracle, ref, dist)
+
+
+def test_set_reference_path_is_bit_identical(scorer):
+    ref = synth.make_ref(640, 360, 41)
+    dists = [synth.distort(ref, "noise", s, seed=s) for s in range(4)]
+    direct = [scorer.compute_ssimu2(ref, d) for d in dists]
+    scorer.set_reference(ref)
+    cached = [scorer.score_against_reference(d) for d in dists]
+    assert direct == cached
+    # and repeatable
+    assert cached == [scorer.score_against_reference(d) for d in dists]
+
+
+def test_device_resident_entry_points(scorer):
+    import torch
+    ref = synth.make_ref(400, 300, 51)
+    dist = synth.distort(ref, "blur", 1)
+    host = scorer.compute_ssimu2(ref, dist)
+    t_ref = torch.from_numpy(ref).cuda()
+    t_dist = torch.from_numpy(dist).cuda()
+    torch.cuda.synchronize()
+    assert scorer.score_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300) == host
+    scorer.enqueue_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300)
+    assert scorer.wait() == host
+    ms, s = scorer.time_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300, 3)
+    assert s == host and ms > 0
+
+
+def test_two_contexts_are_independent(hip_lib, scorer):
+    from oavif_amd import Ssimu2
+    ref = synth.make_ref(320, 200, 61)
+    d1 = synth.distort(ref, "noise", 1)
+    d2 = synth.distort(ref, "blockq", 3)
+    with Ssimu2(0) as other:
+        a = scorer.compute_ssimu2(ref, d1)
+        b = other.compute_ssimu2(ref, d2)
+        assert a == other.compute_ssimu2(ref, d1)
+        assert b == scorer.compute_ssimu2(ref, d2)
+
+
+def test_error_codes(scorer):
+    from oavif_amd import Ssimu2, Ssimu2Error, _lib
+    ref = synth.make_ref(32, 32, 1)
+    with pytest.raises(Ssimu2Error) as ei:
+        scorer.compute_ssimu2(ref, ref, channels=4)     # the reference always passes 3
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    with Ssimu2(0) as fresh:
+        with pytest.raises(Ssimu2Error) as ei:
+            fresh.score_against_reference(ref)
+        assert ei.value.code == _lib.ERR_NO_REFERENCE
+    with pytest.raises(Ssimu2Error) as ei:
+        Ssimu2(99)
+    assert ei.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_published_recursion_gap_reported(scorer, oracle, golden):
+    """HIP (FIR) vs the oracle's fp32-IIR mode: bounded, NOT within 0.01 (documented)."""
+    arrays, meta = golden
+    ref = arrays["ref"]
+    gaps = []
+    for p in meta["pairs"]:
+        gaps.append(scorer.compute_ssimu2(ref, arrays[p["name"]]) - p["score_iir"])
+    assert max(abs(g) for g in gaps) < 0.1
+
+
+# ---- the search: identical probe sequence and final quantizer, CPU scorer vs HIP scorer ------
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+@pytest.mark.parametrize("seed,tgt", [(0, 80.0), (1, 60.0), (2, 90.0), (3, 75.0)])
+def test_search_quantizer_identical_to_cpu(scorer, oracle, seed, tgt):
+    from oavif_amd import tq
+    from oracle import tq_oracle
+    ref = synth.make_ref(384, 256, 100 + seed)
+    cache = {}
+
+    def codec(q):
+        if q not in cache:
+            cache[q] = synth.avif_roundtrip(ref, q, speed=9)
+        return cache[q]
+
+    gpu = tq.search_hip(scorer, ref, codec, score_tgt=tgt, tolerance=2.0, max_pass=6)
+    cpu = tq_oracle.find_target_quality(
+        lambda q: oracle.compute_ssimu2(ref, codec(q)[0], oracle.BLUR_FIR),
+        score_tgt=tgt, tolerance=2.0, max_pass=6)
+    assert [q for q, _ in gpu.history] == [q for q, _ in cpu.history]
+    assert (gpu.q, gpu.num_pass, gpu.buf_q) == (cpu.q, cpu.num_pass, cpu.buf_q)
+    assert max(abs(a[1] - b[1]) for a, b in zip(gpu.history, cpu.history)) <= TOL_SCORE
+    assert gpu.last_avif_size == cache[gpu.buf_q][1]
+
+
+def test_4k_properties(scorer):
+    """BASELINE size (3840x2160): size-independent properties instead of a slow oracle run:
+    identical -> 100, determinism, monotone ladder, set_reference == direct."""
+    ref = synth.make_ref(3840, 2160, 71)
+    assert scorer.compute_ssimu2(ref, ref) == 100.0
+    scores = [scorer.compute_ssimu2(ref, synth.distort(ref, "blockq", s)) for s in (0, 2, 4)]
+    assert scores[0] > scores[1] > scores[2]
+    d = synth.distort(ref, "blockq", 2)
+    assert scorer.compute_ssimu2(ref, d) == scores[1]
+    scorer.set_reference(ref)
+    assert scorer.score_against_reference(d) == scores[1]
+
+
+def test_4k_against_oracle(scorer, oracle):
+    """One full-size oracle comparison (OpenMP build, ~10 s of CPU)."""
+    ref = synth.make_ref(3840, 2160, 72)
+    d = synth.distort(ref, "noise", 2, seed=9)
+    got = scorer.compute_ssimu2(ref, d)
+    exp = oracle.compute_ssimu2(ref, d, oracle.BLUR_FIR, omp=True)
+    assert abs(got - exp) <= TOL_SCORE
