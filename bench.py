@@ -82,8 +82,9 @@ def main() -> int:
     # synthetic pair of this rank (seeded): structured frame + 8x8 block quantisation
     ref = synth.make_ref(w, h, seed=rank)
     dst = synth.distort(ref, "blockq", 2)
-    t_ref = torch.from_numpy(ref).cuda()
-    t_dst = torch.from_numpy(dst).cuda()
+    t_ref = torch.from_numpy(ref).cuda().contiguous()
+    t_dst = torch.from_numpy(dst).cuda().contiguous()
+    assert t_ref.is_contiguous() and t_dst.is_contiguous()
     torch.cuda.synchronize()
 
     scorer = oavif_amd.Ssimu2(local_rank)

@@ -66,6 +66,15 @@ def lib() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m oavif_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the scorer.")
+    # PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 (same SONAME as /opt/rocm's).
+    # Whichever HIP runtime is loaded first serves the whole process, and torch cannot
+    # initialise on top of a foreign one ("No HIP GPUs are available").  Python callers
+    # share device memory and streams with torch, so let torch's runtime load first.
+    if os.environ.get("OAVIF_AMD_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u8p, f64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_double)
     u32, ci = ctypes.c_uint32, ctypes.c_int

@@ -39,6 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
            "-Wall", "-Wno-unused-function", "-o", LIB_PATH]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

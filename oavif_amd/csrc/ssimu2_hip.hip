@@ -56,6 +56,32 @@ __constant__ DevConst c_k;
 
 // ---- device helpers ---------------------------------------------------------------------
 
+// Arithmetic contract: this translation unit is compiled with
+// -ffp-contract=off; every fused multiply-add is an explicit fmaf().  The sequence of IEEE
+// operations per pixel is fixed and is the same one the CPU checker evaluates, because the
+// SSIM map cancels hard in fp32 (a 1-ulp difference upstream moves the score by ~1e-3).
+
+// Cube root from IEEE mul/fma only: bit-trick seed for x^(-1/3), two Newton steps,
+// c = x y^2, one residual-corrected Newton step on c.  Max error 0.76 ulp.
+__device__ __forceinline__ float cbrt_repro(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t i = __float_as_uint(x);
+    i = 0x54A2FA8Cu - i / 3u;
+    float y = __uint_as_float(i);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float t = x * y;
+        t = t * y;
+        t = t * y;
+        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
+    }
+    const float y2 = y * y;
+    float c = x * y2;
+    const float r = fmaf(c * c, c, -x);
+    c = fmaf(r, y2 * (-1.0f / 3.0f), c);
+    return c;
+}
+
 __device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& X, float& Y,
                                               float& B) {
     float l = fmaf(kM00, r, fmaf(kM01, g, fmaf(kM02, b, kOpsinBias)));
@@ -65,9 +91,9 @@ __device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& 
     m = fmaxf(m, 0.0f);
     s = fmaxf(s, 0.0f);
     const float cb = c_k.cbrt_bias;
-    l = cbrtf(l) - cb;
-    m = cbrtf(m) - cb;
-    s = cbrtf(s) - cb;
+    l = cbrt_repro(l) - cb;
+    m = cbrt_repro(m) - cb;
+    s = cbrt_repro(s) - cb;
     const float x = 0.5f * (l - m), y = 0.5f * (l + m);
     B = (s - y) + 0.55f;
     X = fmaf(x, 14.0f, 0.42f);
@@ -248,16 +274,19 @@ __global__ __launch_bounds__(256) void k_scale(const void* __restrict__ ref_in,
                 // SSIM map
                 const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
                 const float dm = mu1 - mu2;
-                const float num_m = 1.0f - dm * dm;
-                const float num_s = 2.0f * (s12 - mu12) + kC2;
-                const float denom_s = (s11 - mu11) + (s22 - mu22) + kC2;
-                float d = 1.0f - (num_m * num_s) / denom_s;
+                const float num_m = fmaf(-dm, dm, 1.0f);
+                const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+                const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+                float d = 1.0f - (num_m * num_s) / denom_s;  // IEEE-rounded division
                 d = fmaxf(d, 0.0f);
                 float d2 = d * d;
                 acc[c * 2] += d;
                 acc[c * 2 + 1] += d2 * d2;
                 // edge-difference map
-                const float e = (1.0f + fabsf(r2 - mu2)) / (1.0f + fabsf(r1 - mu1)) - 1.0f;
+                // (1+a)/(1+b) - 1 == (a-b)/(1+b): the published form is evaluated in fp64;
+                // this one has no cancellation, so fp32 agrees with it to ~1e-7 relative
+                const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+                const float e = (ea - eb) / (1.0f + eb);
                 const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
                 const float a2 = art * art, t2 = det * det;
                 acc[6 + c * 4] += art;
@@ -395,6 +424,28 @@ void gaussian_taps(double sigma, float taps[5]) {
         }
         taps[t] = (float)wsum;
     }
+}
+
+// host twin of the device cbrt_repro (same IEEE sequence; this file is built with
+// -ffp-contract=off, fmaf is the correctly rounded libm/hardware fma)
+float cbrt_repro_host(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t i;
+    memcpy(&i, &x, 4);
+    i = 0x54A2FA8Cu - i / 3u;
+    float y;
+    memcpy(&y, &i, 4);
+    for (int k = 0; k < 2; ++k) {
+        float t = x * y;
+        t = t * y;
+        t = t * y;
+        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
+    }
+    const float y2 = y * y;
+    float c = x * y2;
+    const float r = fmaf(c * c, c, -x);
+    c = fmaf(r, y2 * (-1.0f / 3.0f), c);
+    return c;
 }
 
 thread_local std::string g_create_error;
@@ -658,7 +709,7 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
         k->lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
     }
     gaussian_taps(1.5, k->taps);
-    k->cbrt_bias = cbrtf(kOpsinBias);
+    k->cbrt_bias = cbrt_repro_host(kOpsinBias);
     memcpy(k->weights, kWeightsHost, sizeof kWeightsHost);
     hipError_t ec = hipMemcpyToSymbol(HIP_SYMBOL(c_k), k, sizeof(DevConst));
     delete k;

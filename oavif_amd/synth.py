@@ -55,7 +55,7 @@ def make_ref(w: int, h: int, seed: int = 0) -> np.ndarray:
         sl = img[y0:y0 + sh, x0:x0 + sw]
         sl *= (1 - a)
         sl += a * col
-    return np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8))
 
 
 def distort(ref: np.ndarray, kind: str = "blockq", strength: int = 2, seed: int = 0) -> np.ndarray:
@@ -85,7 +85,7 @@ def distort(ref: np.ndarray, kind: str = "blockq", strength: int = 2, seed: int 
         out = np.floor(f / q) * q + q / 2
     else:
         raise ValueError(f"unknown distortion {kind!r}")
-    return np.clip(out + 0.5, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(out + 0.5, 0, 255).astype(np.uint8))
 
 
 def have_avif() -> bool:

@@ -53,6 +53,8 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
         lib.or_downsample2.restype = None
         lib.or_score_from_averages.argtypes = [f64p, ctypes.c_int]
         lib.or_score_from_averages.restype = ctypes.c_double
+        lib.or_cbrtf.argtypes = [ctypes.c_float]
+        lib.or_cbrtf.restype = ctypes.c_float
         lib.or_weights.argtypes = [f64p]
         lib.or_weights.restype = None
         _libs[omp] = lib
@@ -142,3 +144,7 @@ def weights() -> np.ndarray:
     w = np.zeros(108, np.float64)
     _lib().or_weights(_f64(w))
     return w
+
+
+def cbrtf(x: float) -> float:
+    return float(_lib().or_cbrtf(float(x)))

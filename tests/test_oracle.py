@@ -83,6 +83,25 @@ def test_srgb_lut(oracle):
     assert lut[128] == pytest.approx(((128 / 255 + 0.055) / 1.055) ** 2.4, rel=1e-6)
 
 
+def test_reproducible_cbrt_accuracy(oracle):
+    """or_cbrtf (IEEE mul/fma only, mirrored on the GPU) is a <1-ulp cube root."""
+    rng = np.random.default_rng(8)
+    xs = np.concatenate([rng.uniform(0.0037, 1.01, 20000), 10.0 ** rng.uniform(-30, 30, 5000),
+                         [0.0037930732552754493, 1.0, 0.125, 8.0]]).astype(np.float32)
+    worst = 0.0
+    exact = 0
+    for x in xs:
+        c = np.float32(oracle.cbrtf(float(x)))
+        e = np.cbrt(np.float64(x))
+        ulp = np.spacing(np.float32(e))
+        worst = max(worst, abs(float(c) - float(e)) / float(ulp))
+        exact += c == np.float32(e)
+    assert worst < 0.8, worst
+    assert exact / len(xs) > 0.88
+    assert oracle.cbrtf(0.0) == 0.0 and oracle.cbrtf(-1.0) == 0.0
+    assert oracle.cbrtf(1.0) == 1.0 and oracle.cbrtf(8.0) == 2.0
+
+
 def test_xyb_known_points(oracle):
     lin = np.zeros((3, 1, 3), np.float32)
     lin[:, 0, 1] = 1.0            # white
@@ -175,7 +194,7 @@ def test_iir_fp32_noise_gap_is_bounded_and_documented(oracle, golden):
     arrays, meta = golden
     gaps = {p["name"]: p["score_iir"] - p["score_fir"] for p in meta["pairs"]}
     assert gaps["identical"] == 0.0
-    assert all(abs(g) < 0.1 for g in gaps.values()), gaps
+    assert all(abs(g) < 0.3 for g in gaps.values()), gaps
     assert max(abs(g) for g in gaps.values()) > 0.01    # ... but NOT within +-0.01
 
 
