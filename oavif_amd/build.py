@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
+           "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
            "-Wall", "-Wno-unused-function", "-o", LIB_PATH]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -26,10 +26,12 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "../../include/ssimu2_hip.h"
 
@@ -313,6 +315,259 @@ __global__ __launch_bounds__(256) void k_scale(const void* __restrict__ ref_in,
     }
 }
 
+// ---- per-scale fused kernel, marching form ---------------------------------------------------
+// One workgroup (8 waves) owns a strip of MW output columns and marches down `seg_rows`
+// output rows, one image row per step.
+//   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128).  Each step they
+//     convert the next input row of both frames (sRGB LUT at scale 0 -> opsin -> cbrt ->
+//     positive XYB) into an LDS ring of raw rows; the global loads for the row after that are
+//     issued first, so their latency spans a whole step.
+//   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
+//     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
+//     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
+//     registers and pushes the results into a 9-row register window, from which the
+//     vertical 9-tap and the SSIM / edge-difference maps of the row four steps back are
+//     evaluated and accumulated.  The row loop is unrolled nine times so the window is
+//     addressed with compile-time indices (no register moves).
+// One output pixel per lane keeps the window at 45 registers (<= 128 VGPRs, 4 waves/SIMD):
+// with a lone wave issuing a VALU op only every 4 cycles, occupancy is what fills the SIMDs.
+// HBM traffic: each input pixel is read once per strip (+8/MW horizontal, +8/seg_rows
+// vertical halo); only 18 partial sums per workgroup are written.
+constexpr int MW = 120;        // output columns per strip
+constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 converter waves
+constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
+constexpr int RING = 8;        // raw-row ring depth (power of two >= 6)
+constexpr int MARCH_THREADS = 512;
+
+// Correctly rounded a / b for operands that need no exponent scaling (here b is in
+// [9e-4, 4], |a| < 4): v_rcp_f32 seed, one Newton step on the reciprocal, two fused
+// residual corrections of the quotient -- the sequence hipcc emits for `a / b` minus
+// v_div_scale / v_div_fixup, which only act on out-of-range exponents.  Same bits as the
+// IEEE division the CPU checker performs.
+__device__ __forceinline__ float div_rn(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = fmaf(-b, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = fmaf(-b, q, a);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-b, q, a);
+    return fmaf(e2, r, q);
+}
+
+// Raw values of one staged pixel of an input row: 2 frames x RGB.
+template <bool kU8>
+struct MarchRaw {
+    typename std::conditional<kU8, uint32_t, float>::type v[2][3];
+    bool ok;
+};
+
+// Issue the global loads of input row r, staged column `col` (global x = x0 - 4 + col).
+template <bool kU8>
+__device__ __forceinline__ void march_load(MarchRaw<kU8>& raw, const void* __restrict__ ref_in,
+                                           const void* __restrict__ dist_in, int w, int h, int x0,
+                                           int r, int col) {
+    const int gx = x0 - RAD + col;
+    raw.ok = r >= 0 && r < h && gx >= 0 && gx < w;
+    const size_t n = (size_t)w * h;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        raw.v[k][0] = raw.v[k][1] = raw.v[k][2] = 0;
+        if (raw.ok) {
+            if constexpr (kU8) {
+                const uint8_t* p = (const uint8_t*)(k ? dist_in : ref_in) + ((size_t)r * w + gx) * 3;
+                raw.v[k][0] = p[0];
+                raw.v[k][1] = p[1];
+                raw.v[k][2] = p[2];
+            } else {
+                const float* p = (const float*)(k ? dist_in : ref_in) + (size_t)r * w + gx;
+                raw.v[k][0] = p[0];
+                raw.v[k][1] = p[n];
+                raw.v[k][2] = p[2 * n];
+            }
+        }
+    }
+}
+
+// Convert the loaded pixel to positive XYB and store it into ring slot `slot` (zeros outside
+// the image: the blur is zero padded).
+template <bool kU8>
+__device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const float* lut,
+                                              const MarchRaw<kU8>& raw, int slot, int col) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float rr, gg, bb, v[3];
+        if constexpr (kU8) {
+            rr = lut[raw.v[k][0]];
+            gg = lut[raw.v[k][1]];
+            bb = lut[raw.v[k][2]];
+        } else {
+            rr = raw.v[k][0];
+            gg = raw.v[k][1];
+            bb = raw.v[k][2];
+        }
+        linear_to_xyb(rr, gg, bb, v[0], v[1], v[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&win)[5][9],
+                                              float (&acc)[6], int t, int ch, int o, bool ok,
+                                              float w0, float w1, float w2, float w3, float w4) {
+    const int slot = t & (RING - 1);
+    const float* px = &ring[slot][0][ch][o];  // staged columns o .. o+8, centre o+4
+    const float* py = &ring[slot][1][ch][o];
+    float xv[9], yv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        xv[q] = px[q];
+        yv[q] = py[q];
+    }
+#define H9(e) \
+    fir9(e(4), e(3) + e(5), e(2) + e(6), e(1) + e(7), e(0) + e(8), w0, w1, w2, w3, w4)
+#define EX(q) xv[q]
+#define EY(q) yv[q]
+#define EXX(q) (xv[q] * xv[q])
+#define EYY(q) (yv[q] * yv[q])
+#define EXY(q) (xv[q] * yv[q])
+    win[0][P] = H9(EX);
+    win[1][P] = H9(EY);
+    win[2][P] = H9(EXX);
+    win[3][P] = H9(EYY);
+    win[4][P] = H9(EXY);
+#undef EX
+#undef EY
+#undef EXX
+#undef EYY
+#undef EXY
+#undef H9
+    if (t >= 8) {  // window full (uniform across the workgroup)
+        // vertical 9-tap for the row four steps back: row t-j sits in window slot (P-j) mod 9
+        const int cslot = (t - 4) & (RING - 1);
+        const float r1 = ring[cslot][0][ch][o + RAD];
+        const float r2 = ring[cslot][1][ch][o + RAD];
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float* q = win[k];
+            v[k] = fir9(q[(P + 5) % 9], q[(P + 4) % 9] + q[(P + 6) % 9],
+                        q[(P + 3) % 9] + q[(P + 7) % 9], q[(P + 2) % 9] + q[(P + 8) % 9],
+                        q[(P + 1) % 9] + q[P], w0, w1, w2, w3, w4);
+        }
+        const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
+        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+        const float dm = mu1 - mu2;
+        const float num_m = fmaf(-dm, dm, 1.0f);
+        const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+        const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+        float d = 1.0f - div_rn(num_m * num_s, denom_s);
+        d = fmaxf(d, 0.0f);
+        const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+        float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
+        d = ok ? d : 0.0f;                      // column inside the image?
+        e = ok ? e : 0.0f;
+        const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
+        const float d2 = d * d, a2 = art * art, t2 = det * det;
+        acc[0] += d;
+        acc[1] += d2 * d2;
+        acc[2] += art;
+        acc[3] += a2 * a2;
+        acc[4] += det;
+        acc[5] += t2 * t2;
+    }
+}
+
+template <bool kU8>
+__global__ __launch_bounds__(MARCH_THREADS, 2) void k_march(const void* __restrict__ ref_in,
+                                                            const void* __restrict__ dist_in,
+                                                            int w, int h, int seg_rows,
+                                                            double* __restrict__ partials,
+                                                            int nblocks) {
+    __shared__ __attribute__((aligned(16))) float s_ring[RING][2][3][MRW];
+    __shared__ float s_lut[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * MW;
+    const int y0 = blockIdx.y * seg_rows;
+    const int rows_out = min(seg_rows, h - y0);
+    const int steps = rows_out + 2 * RAD;  // input rows y0-4 .. y0+rows_out+3
+    if (kU8 && tid < 256) s_lut[tid] = c_k.lut[tid];
+    __syncthreads();
+
+    const float w0 = c_k.taps[0], w1 = c_k.taps[1], w2 = c_k.taps[2], w3 = c_k.taps[3],
+                w4 = c_k.taps[4];
+    const bool is_conv = wave < 2;
+    // converter state
+    const int col = tid & (MRW - 1);
+    MarchRaw<kU8> cur, nxt;
+    // blur state (fp32 sums: at most seg_rows <= 128 terms per lane before the fp64 reduce)
+    float win[5][9];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int hw = wave - 2;
+    const int ch = hw >> 1;
+    const bool hv_active = lane < MHALF;
+    const int o = (hw & 1) * MHALF + (hv_active ? lane : 0);
+    const bool ok = x0 + o < w;
+
+    if (is_conv) {
+        march_load<kU8>(cur, ref_in, dist_in, w, h, x0, y0 - RAD, col);
+        march_load<kU8>(nxt, ref_in, dist_in, w, h, x0, y0 - RAD + 1, col);
+        march_convert<kU8>(s_ring, s_lut, cur, 0, col);
+        cur = nxt;
+    }
+    __syncthreads();
+
+#define MARCH_STEP(P)                                                                          \
+    {                                                                                          \
+        const int t = t0 + P;                                                                  \
+        if (t < steps) {                                                                       \
+            if (is_conv) {                                                                     \
+                if (t + 1 < steps) {                                                           \
+                    march_load<kU8>(nxt, ref_in, dist_in, w, h, x0, y0 - RAD + t + 2, col);    \
+                    march_convert<kU8>(s_ring, s_lut, cur, (t + 1) & (RING - 1), col);         \
+                    cur = nxt;                                                                 \
+                }                                                                              \
+            } else {                                                                           \
+                march_hv_step<P>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4);          \
+            }                                                                                  \
+            __syncthreads();                                                                   \
+        }                                                                                      \
+    }
+#pragma unroll 1
+    for (int t0 = 0; t0 < steps; t0 += 9) {
+        MARCH_STEP(0)
+        MARCH_STEP(1)
+        MARCH_STEP(2)
+        MARCH_STEP(3)
+        MARCH_STEP(4)
+        MARCH_STEP(5)
+        MARCH_STEP(6)
+        MARCH_STEP(7)
+        MARCH_STEP(8)
+    }
+#undef MARCH_STEP
+
+    // the two half-strip waves of a channel each publish their sums; combined in fixed order
+    __shared__ double s_part[6][6];
+    if (!is_conv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double v = wave_sum(hv_active ? (double)acc[k] : 0.0);
+            if (lane == 0) s_part[hw][k] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < kStats) {
+        // tid = stat index: 0..5 ssim (c*2+n), 6..17 edge (c*4+k)
+        const int c = tid < 6 ? tid >> 1 : (tid - 6) >> 2;
+        const int k = tid < 6 ? (tid & 1) : 2 + ((tid - 6) & 3);
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        partials[(size_t)tid * nblocks + blk] = s_part[2 * c][k] + s_part[2 * c + 1][k];
+    }
+}
+
 // ---- final reduction ----------------------------------------------------------------------
 struct ScaleInfo {
     int nblocks[kNumScales];
@@ -477,6 +732,9 @@ struct ssimu2_ctx {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+    bool use_march = true;  // marching kernel (default) vs tile kernel (OAVIF_AMD_KERNEL=tile)
+    int seg_rows_override = 0;
+
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
         if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
@@ -537,19 +795,35 @@ void free_buffers(ssimu2_ctx* c) {
     c->partial_cap = 0;
 }
 
-size_t partial_doubles(const Pyramid& p) {
-    size_t t = 0;
-    for (int s = 0; s < p.nscales; ++s) {
-        const size_t nb = (size_t)((p.w[s] + TX - 1) / TX) * ((p.h[s] + TY - 1) / TY);
-        t += nb * kStats;
+// Rows per workgroup of the marching kernel: aim at ~1100 workgroups per scale (about two
+// resident rounds of the 256 CUs) but never fewer than 8 rows (halo cost) nor more than 128.
+int march_seg_rows(const ssimu2_ctx* c, int w, int h) {
+    if (c->seg_rows_override > 0) return c->seg_rows_override;
+    const int nstrips = (w + MW - 1) / MW;
+    int seg = (int)(((long long)h * nstrips + 1099) / 1100);
+    if (seg < 8) seg = 8;
+    if (seg > 128) seg = 128;
+    return seg;
+}
+
+int scale_blocks(const ssimu2_ctx* c, const Pyramid& p, int s) {
+    if (c->use_march) {
+        const int seg = march_seg_rows(c, p.w[s], p.h[s]);
+        return ((p.w[s] + MW - 1) / MW) * ((p.h[s] + seg - 1) / seg);
     }
+    return ((p.w[s] + TX - 1) / TX) * ((p.h[s] + TY - 1) / TY);
+}
+
+size_t partial_doubles(const ssimu2_ctx* c, const Pyramid& p) {
+    size_t t = 0;
+    for (int s = 0; s < p.nscales; ++s) t += (size_t)scale_blocks(c, p, s) * kStats;
     return t;
 }
 
 int ensure_capacity(ssimu2_ctx* c, uint32_t w, uint32_t h) {
     const Pyramid p = make_pyramid(w, h);
     const size_t need_u8 = (size_t)w * h * 3, need_lin = p.lin_total + 4,
-                 need_part = partial_doubles(p) + 8;
+                 need_part = partial_doubles(c, p) + 8;
     if (c->d_ref_u8 && need_u8 <= c->cap_u8 && need_lin <= c->cap_lin &&
         need_part <= c->partial_cap)
         return SSIMU2_OK;
@@ -575,21 +849,28 @@ int ensure_capacity(ssimu2_ctx* c, uint32_t w, uint32_t h) {
     return SSIMU2_OK;
 }
 
-int scale_blocks(const Pyramid& p, int s) {
-    return ((p.w[s] + TX - 1) / TX) * ((p.h[s] + TY - 1) / TY);
-}
-
 void launch_scale(ssimu2_ctx* c, const Pyramid& p, int s, const uint8_t* d_ref,
                   const uint8_t* d_dist, double* part) {
+    const void* a = s == 0 ? (const void*)d_ref : (const void*)(c->d_lin_ref + p.lin_off[s]);
+    const void* b = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
+    const int nb = scale_blocks(c, p, s);
+    if (c->use_march) {
+        const int seg = march_seg_rows(c, p.w[s], p.h[s]);
+        dim3 grid((p.w[s] + MW - 1) / MW, (p.h[s] + seg - 1) / seg), block(MARCH_THREADS);
+        if (s == 0)
+            hipLaunchKernelGGL(k_march<true>, grid, block, 0, c->stream, a, b, p.w[s], p.h[s], seg,
+                               part, nb);
+        else
+            hipLaunchKernelGGL(k_march<false>, grid, block, 0, c->stream, a, b, p.w[s], p.h[s],
+                               seg, part, nb);
+        return;
+    }
     dim3 grid((p.w[s] + TX - 1) / TX, (p.h[s] + TY - 1) / TY), block(256);
-    const int nb = (int)(grid.x * grid.y);
     if (s == 0)
-        hipLaunchKernelGGL(k_scale<true>, grid, block, 0, c->stream, (const void*)d_ref,
-                           (const void*)d_dist, p.w[s], p.h[s], part, nb);
+        hipLaunchKernelGGL(k_scale<true>, grid, block, 0, c->stream, a, b, p.w[s], p.h[s], part, nb);
     else
-        hipLaunchKernelGGL(k_scale<false>, grid, block, 0, c->stream,
-                           (const void*)(c->d_lin_ref + p.lin_off[s]),
-                           (const void*)(c->d_lin_dist + p.lin_off[s]), p.w[s], p.h[s], part, nb);
+        hipLaunchKernelGGL(k_scale<false>, grid, block, 0, c->stream, a, b, p.w[s], p.h[s], part,
+                           nb);
 }
 
 // Enqueue the whole score of (d_ref, d_dist) on the ctx stream.  `ref_pyramid_ready`:
@@ -628,7 +909,7 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
     }
     // 2. per-scale fused kernel
     for (int s = 0; s < p.nscales; ++s) {
-        const int nb = scale_blocks(p, s);
+        const int nb = scale_blocks(c, p, s);
         si.nblocks[s] = nb;
         si.offset[s] = (long long)poff;
         si.inv_pixels[s] = 1.0 / ((double)p.w[s] * (double)p.h[s]);
@@ -658,7 +939,7 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v1 (tile kernels)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v2 (marching kernels)"; }
 
 const char* ssimu2_last_error(const ssimu2_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
@@ -678,6 +959,8 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     ssimu2_ctx* c = new (std::nothrow) ssimu2_ctx();
     if (!c) return SSIMU2_ERR_OOM;
     c->device = device;
+    if (const char* k = getenv("OAVIF_AMD_KERNEL")) c->use_march = strcmp(k, "tile") != 0;
+    if (const char* k = getenv("OAVIF_AMD_SEG_ROWS")) c->seg_rows_override = atoi(k);
 #define CREATE_TRY(call)                                   \
     do {                                                   \
         hipError_t e2 = (call);                            \
@@ -858,7 +1141,7 @@ int ssimu2_time_scale_kernel(ssimu2_ctx* c, const void* d_ref, const void* d_dis
     const Pyramid p = make_pyramid(w, h);
     if (scale < 0 || scale >= p.nscales) return c->fail(SSIMU2_ERR_INVALID_ARG, "bad scale");
     size_t poff = 0;
-    for (int s = 0; s < scale; ++s) poff += (size_t)scale_blocks(p, s) * kStats;
+    for (int s = 0; s < scale; ++s) poff += (size_t)scale_blocks(c, p, s) * kStats;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < iters; ++i)
         launch_scale(c, p, scale, (const uint8_t*)d_ref, (const uint8_t*)d_dist,

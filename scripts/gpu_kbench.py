@@ -1,0 +1,18 @@
+"""Kernel micro-bench on the GPU box: per-scale fused-kernel time and whole-score time at 4K."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import oavif_amd
+from oavif_amd import synth
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+ref = synth.make_ref(w, h, 0); dst = synth.distort(ref, "blockq", 2)
+tr = torch.from_numpy(ref).cuda().contiguous(); td = torch.from_numpy(dst).cuda().contiguous()
+torch.cuda.synchronize()
+s = oavif_amd.Ssimu2(0)
+score = s.score_device(tr.data_ptr(), td.data_ptr(), w, h)
+_, ns = s.last_averages()
+ks = [s.time_scale_kernel(tr.data_ptr(), td.data_ptr(), w, h, sc, 30) * 1e3 for sc in range(ns)]
+ms, _ = s.time_device(tr.data_ptr(), td.data_ptr(), w, h, 50)
+tag = f"kernel={os.environ.get('OAVIF_AMD_KERNEL','march')} seg={os.environ.get('OAVIF_AMD_SEG_ROWS','auto')}"
+print(f"{tag}: score={score:.9f} scale_us={[round(k,1) for k in ks]} sum={sum(ks):.1f} whole_score_us={ms/50*1e3:.1f} MP/s={w*h/1e6/(ms/50/1e3):.0f}")
