@@ -66,7 +66,6 @@ __constant__ DevConst c_k;
 // Cube root from IEEE mul/fma only: bit-trick seed for x^(-1/3), two Newton steps,
 // c = x y^2, one residual-corrected Newton step on c.  Max error 0.76 ulp.
 __device__ __forceinline__ float cbrt_repro(float x) {
-    if (!(x > 0.0f)) return 0.0f;
     uint32_t i = __float_as_uint(x);
     i = 0x54A2FA8Cu - i / 3u;
     float y = __uint_as_float(i);
@@ -81,7 +80,7 @@ __device__ __forceinline__ float cbrt_repro(float x) {
     float c = x * y2;
     const float r = fmaf(c * c, c, -x);
     c = fmaf(r, y2 * (-1.0f / 3.0f), c);
-    return c;
+    return x > 0.0f ? c : 0.0f;  // branch-free guard (inputs are clamped to >= 0)
 }
 
 __device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& X, float& Y,
@@ -316,13 +315,13 @@ __global__ __launch_bounds__(256) void k_scale(const void* __restrict__ ref_in,
 }
 
 // ---- per-scale fused kernel, marching form ---------------------------------------------------
-// One workgroup (8 waves) owns a strip of MW output columns and marches down `seg_rows`
+// One workgroup (10 waves) owns a strip of MW output columns and marches down `seg_rows`
 // output rows, one image row per step.
-//   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128).  Each step they
-//     convert the next input row of both frames (sRGB LUT at scale 0 -> opsin -> cbrt ->
-//     positive XYB) into an LDS ring of raw rows; the global loads for the row after that are
-//     issued first, so their latency spans a whole step.
-//   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
+//   waves 0-3 (converters): lane = one staged column (MW + 8 halo = 128) of one frame.  Each
+//     step they convert the next input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive
+//     XYB) into an LDS ring of raw rows; the global loads for the row after that are issued
+//     first, so their latency spans a whole step.
+//   waves 4-9 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
 //     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
 //     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
 //     registers and pushes the results into a 9-row register window, from which the
@@ -334,10 +333,13 @@ __global__ __launch_bounds__(256) void k_scale(const void* __restrict__ ref_in,
 // HBM traffic: each input pixel is read once per strip (+8/MW horizontal, +8/seg_rows
 // vertical halo); only 18 partial sums per workgroup are written.
 constexpr int MW = 120;        // output columns per strip
-constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 converter waves
+constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 waves per frame
 constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
-constexpr int RING = 8;        // raw-row ring depth (power of two >= 6)
-constexpr int MARCH_THREADS = 512;
+constexpr int RING = 16;       // raw-row ring depth (power of two >= 10: rows t-4 .. t+5)
+constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
+constexpr int MARCH_THREADS = 640;
+constexpr int CONV_WAVES = 4;
+constexpr int PF = 4;  // rows the converters' global loads run ahead of the conversion
 
 // Correctly rounded a / b for operands that need no exponent scaling (here b is in
 // [9e-4, 4], |a| < 4): v_rcp_f32 seed, one Newton step on the reciprocal, two fused
@@ -355,61 +357,54 @@ __device__ __forceinline__ float div_rn(float a, float b) {
     return fmaf(e2, r, q);
 }
 
-// Raw values of one staged pixel of an input row: 2 frames x RGB.
+// Raw values of one staged pixel of one frame of an input row.
 template <bool kU8>
 struct MarchRaw {
-    typename std::conditional<kU8, uint32_t, float>::type v[2][3];
+    typename std::conditional<kU8, uint32_t, float>::type v[3];
     bool ok;
 };
 
 // Issue the global loads of input row r, staged column `col` (global x = x0 - 4 + col).
 template <bool kU8>
-__device__ __forceinline__ void march_load(MarchRaw<kU8>& raw, const void* __restrict__ ref_in,
-                                           const void* __restrict__ dist_in, int w, int h, int x0,
-                                           int r, int col) {
+__device__ __forceinline__ void march_load(MarchRaw<kU8>& raw, const void* __restrict__ img, int w,
+                                           int h, int x0, int r, int col) {
     const int gx = x0 - RAD + col;
     raw.ok = r >= 0 && r < h && gx >= 0 && gx < w;
-    const size_t n = (size_t)w * h;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        raw.v[k][0] = raw.v[k][1] = raw.v[k][2] = 0;
-        if (raw.ok) {
-            if constexpr (kU8) {
-                const uint8_t* p = (const uint8_t*)(k ? dist_in : ref_in) + ((size_t)r * w + gx) * 3;
-                raw.v[k][0] = p[0];
-                raw.v[k][1] = p[1];
-                raw.v[k][2] = p[2];
-            } else {
-                const float* p = (const float*)(k ? dist_in : ref_in) + (size_t)r * w + gx;
-                raw.v[k][0] = p[0];
-                raw.v[k][1] = p[n];
-                raw.v[k][2] = p[2 * n];
-            }
+    raw.v[0] = raw.v[1] = raw.v[2] = 0;
+    if (raw.ok) {
+        if constexpr (kU8) {
+            const uint8_t* p = (const uint8_t*)img + ((size_t)r * w + gx) * 3;
+            raw.v[0] = p[0];
+            raw.v[1] = p[1];
+            raw.v[2] = p[2];
+        } else {
+            const size_t n = (size_t)w * h;
+            const float* p = (const float*)img + (size_t)r * w + gx;
+            raw.v[0] = p[0];
+            raw.v[1] = p[n];
+            raw.v[2] = p[2 * n];
         }
     }
 }
 
-// Convert the loaded pixel to positive XYB and store it into ring slot `slot` (zeros outside
-// the image: the blur is zero padded).
+// Convert the loaded pixel to positive XYB and store it into ring slot `slot` of frame k
+// (zeros outside the image: the blur is zero padded).
 template <bool kU8>
 __device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const float* lut,
-                                              const MarchRaw<kU8>& raw, int slot, int col) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        float rr, gg, bb, v[3];
-        if constexpr (kU8) {
-            rr = lut[raw.v[k][0]];
-            gg = lut[raw.v[k][1]];
-            bb = lut[raw.v[k][2]];
-        } else {
-            rr = raw.v[k][0];
-            gg = raw.v[k][1];
-            bb = raw.v[k][2];
-        }
-        linear_to_xyb(rr, gg, bb, v[0], v[1], v[2]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
+                                              const MarchRaw<kU8>& raw, int slot, int k, int col) {
+    float rr, gg, bb, v[3];
+    if constexpr (kU8) {
+        rr = lut[raw.v[0]];
+        gg = lut[raw.v[1]];
+        bb = lut[raw.v[2]];
+    } else {
+        rr = raw.v[0];
+        gg = raw.v[1];
+        bb = raw.v[2];
     }
+    linear_to_xyb(rr, gg, bb, v[0], v[1], v[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
 }
 
 template <int P>
@@ -480,7 +475,7 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
 }
 
 template <bool kU8>
-__global__ __launch_bounds__(MARCH_THREADS, 2) void k_march(const void* __restrict__ ref_in,
+__global__ __launch_bounds__(MARCH_THREADS) void k_march(const void* __restrict__ ref_in,
                                                             const void* __restrict__ dist_in,
                                                             int w, int h, int seg_rows,
                                                             double* __restrict__ partials,
@@ -498,24 +493,34 @@ __global__ __launch_bounds__(MARCH_THREADS, 2) void k_march(const void* __restri
 
     const float w0 = c_k.taps[0], w1 = c_k.taps[1], w2 = c_k.taps[2], w3 = c_k.taps[3],
                 w4 = c_k.taps[4];
-    const bool is_conv = wave < 2;
-    // converter state
-    const int col = tid & (MRW - 1);
-    MarchRaw<kU8> cur, nxt;
-    // blur state (fp32 sums: at most seg_rows <= 128 terms per lane before the fp64 reduce)
+    const bool is_conv = wave < CONV_WAVES;
+    // converter state: wave -> (frame, half of the staged columns)
+    const int frame = wave >> 1;
+    const int col = ((wave & 1) << 6) + lane;
+    const void* img = frame ? dist_in : ref_in;
+    MarchRaw<kU8> q[PF], nxt;  // q[0] = next row to convert, q[PF-1] = newest loaded
+    // blur state (fp32 sums: at most seg_rows <= 135 terms per lane before the fp64 reduce)
     float win[5][9];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int hw = wave - 2;
+    const int hw = wave - CONV_WAVES;
     const int ch = hw >> 1;
     const bool hv_active = lane < MHALF;
     const int o = (hw & 1) * MHALF + (hv_active ? lane : 0);
     const bool ok = x0 + o < w;
 
+    // Input row j (= image row y0-4+j) lives in ring slot j & (RING-1).  The workgroup
+    // synchronises once per GROUP rows: while the blur waves consume rows 3I..3I+2 the
+    // converters fill rows 3I+3..3I+5.  Global loads run PF rows ahead of the conversion so
+    // HBM latency is off the critical path.
     if (is_conv) {
-        march_load<kU8>(cur, ref_in, dist_in, w, h, x0, y0 - RAD, col);
-        march_load<kU8>(nxt, ref_in, dist_in, w, h, x0, y0 - RAD + 1, col);
-        march_convert<kU8>(s_ring, s_lut, cur, 0, col);
-        cur = nxt;
+        MarchRaw<kU8> first[GROUP];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) march_load<kU8>(first[j], img, w, h, x0, y0 - RAD + j, col);
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            march_load<kU8>(q[j], img, w, h, x0, y0 - RAD + GROUP + j, col);
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) march_convert<kU8>(s_ring, s_lut, first[j], j, frame, col);
     }
     __syncthreads();
 
@@ -524,16 +529,18 @@ __global__ __launch_bounds__(MARCH_THREADS, 2) void k_march(const void* __restri
         const int t = t0 + P;                                                                  \
         if (t < steps) {                                                                       \
             if (is_conv) {                                                                     \
-                if (t + 1 < steps) {                                                           \
-                    march_load<kU8>(nxt, ref_in, dist_in, w, h, x0, y0 - RAD + t + 2, col);    \
-                    march_convert<kU8>(s_ring, s_lut, cur, (t + 1) & (RING - 1), col);         \
-                    cur = nxt;                                                                 \
+                if (t + GROUP < steps) {                                                       \
+                    march_load<kU8>(nxt, img, w, h, x0, y0 - RAD + t + GROUP + PF, col);       \
+                    march_convert<kU8>(s_ring, s_lut, q[0], (t + GROUP) & (RING - 1), frame,   \
+                                       col);                                                   \
+                    _Pragma("unroll") for (int j = 0; j + 1 < PF; ++j) q[j] = q[j + 1];        \
+                    q[PF - 1] = nxt;                                                           \
                 }                                                                              \
             } else {                                                                           \
                 march_hv_step<P>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4);          \
             }                                                                                  \
-            __syncthreads();                                                                   \
         }                                                                                      \
+        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) __syncthreads();              \
     }
 #pragma unroll 1
     for (int t0 = 0; t0 < steps; t0 += 9) {
@@ -795,14 +802,17 @@ void free_buffers(ssimu2_ctx* c) {
     c->partial_cap = 0;
 }
 
-// Rows per workgroup of the marching kernel: aim at ~1100 workgroups per scale (about two
-// resident rounds of the 256 CUs) but never fewer than 8 rows (halo cost) nor more than 128.
+// Rows per workgroup of the marching kernel.  Two 10-wave workgroups fit a CU, so 512
+// workgroups are one fully balanced resident round of the 256 CUs; aim at that, but keep a
+// segment between 8 rows (vertical halo cost 8/seg) and 160 rows (fp32 partial sums).
 int march_seg_rows(const ssimu2_ctx* c, int w, int h) {
     if (c->seg_rows_override > 0) return c->seg_rows_override;
     const int nstrips = (w + MW - 1) / MW;
-    int seg = (int)(((long long)h * nstrips + 1099) / 1100);
+    int nsegs = (512 + nstrips / 2) / nstrips;
+    if (nsegs < 1) nsegs = 1;
+    int seg = (h + nsegs - 1) / nsegs;
     if (seg < 8) seg = 8;
-    if (seg > 128) seg = 128;
+    if (seg > 160) seg = 160;
     return seg;
 }
 
