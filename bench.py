@@ -34,13 +34,16 @@ if ROOT not in sys.path:
 W, H = 3840, 2160
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# SURVEY.md 8(d) W-model, bytes per scale-0 pixel, for what the scale-0 kernel covers in
-# the algorithmic model: read u8 RGB of both frames (6), write XYB_0 of both (24), blur
-# stage reads XYB_0 of both (24).  (The 2x2 downsample to scale 1 -- 6 B/px written -- is
-# a separate kernel in this round and is not credited to this kernel.)
-ALGO_BYTES_PER_PX_SCALE0 = 6 + 24 + 24
-# whole score, all six scales: 85.97 B per scale-0 pixel
+# SURVEY.md 8(d) W-model: 85.97 algorithmic bytes per scale-0 pixel for one whole score
+# (scale 0 reads 6 B/px of u8; every scale writes XYB_s and the blur stage reads it back,
+# 48 B per pixel of that scale; scales >= 1 read linear_s, 24 B; every scale writes
+# linear_{s+1}, 24 B per pixel of the next scale).  The dominant kernel -- the single fused
+# marching launch over all six scales -- covers everything except the linear_{s+1} writes
+# (done by the pyramid kernel): 85.97 - 24 * (1/4 + 1/16 + ...) = 85.97 - 8.00 = 77.97 B/px.
 ALGO_BYTES_PER_PX_SCORE = 85.97
+ALGO_BYTES_PER_PX_MARCH = 77.97
+# blur-pyramid-only model of north_star's ">= 70 % HBM-read roofline" target (B-model)
+ALGO_BYTES_PER_PX_BLUR = 31.99
 
 
 def main() -> int:
@@ -145,22 +148,29 @@ def main() -> int:
         }
 
         # ---- roofline of the dominant kernel, measured live with HIP events ----------------
+        from oavif_amd import _lib
         iters = 50
-        k_ms = scorer.time_scale_kernel(p_ref, p_dst, w, h, 0, iters)
-        algo_bytes = ALGO_BYTES_PER_PX_SCALE0 * w * h
+        k_ms = scorer.time_stage(p_ref, p_dst, w, h, _lib.STAGE_MARCH, iters)
+        pyr_ms = scorer.time_stage(p_ref, p_dst, w, h, _lib.STAGE_PYRAMID, iters)
+        fin_ms = scorer.time_stage(p_ref, p_dst, w, h, _lib.STAGE_FINALIZE, iters)
+        algo_bytes = ALGO_BYTES_PER_PX_MARCH * w * h
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("scale0_hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("march_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_scale<u8> (scale 0 fused XYB+blur+maps)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_march (fused XYB + blur + maps, all 6 scales)",
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(algo_bytes),
-                           "model": "SURVEY 8(d) W-model, scale-0 share: 54 B/px"}
+                           "model": "SURVEY 8(d) W-model minus the pyramid writes: 77.97 B/px",
+                           "blur_pyramid_frac_if_all_time_were_blur": round(
+                               ALGO_BYTES_PER_PX_BLUR * w * h / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["stages_ms"] = {"pyramid": round(pyr_ms, 5), "march": round(k_ms, 5),
+                            "finalize": round(fin_ms, 5)}
         # whole-score view (all kernels of one score, W-model 85.97 B/px)
         ms_total, _ = scorer.time_device(p_ref, p_dst, w, h, 20)
         score_ms = ms_total / 20

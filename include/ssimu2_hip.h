@@ -95,12 +95,15 @@ int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_
 int ssimu2_time_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
                        uint32_t h, int iters, float* out_ms_total, double* out_score);
 
-/* Roofline hook for bench.py: average device milliseconds of ONE launch of the fused
-   per-scale kernel of scale `scale` (0 = full resolution, the dominant kernel), measured
-   with HIP events on the ctx stream around `iters` back-to-back launches.  Runs one full
-   score first so the pyramid the kernel reads is valid. */
-int ssimu2_time_scale_kernel(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
-                             uint32_t h, int scale, int iters, float* out_ms_avg);
+/* Roofline hook for bench.py: average device milliseconds of one execution of a stage of
+   the score, measured with HIP events on the ctx stream around `iters` back-to-back
+   repetitions of that stage alone (a full score runs first so every input is valid).
+   SSIMU2_STAGE_MARCH is the single fused launch that covers all six scales (the dominant
+   kernel); SSIMU2_STAGE_PYRAMID the 1-2 launches that build the linear-light pyramid;
+   SSIMU2_STAGE_FINALIZE the final reduction. */
+enum { SSIMU2_STAGE_PYRAMID = 0, SSIMU2_STAGE_MARCH = 1, SSIMU2_STAGE_FINALIZE = 2 };
+int ssimu2_time_stage(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
+                      uint32_t h, int stage, int iters, float* out_ms_avg);
 
 /* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v1". */
 const char* ssimu2_version(void);

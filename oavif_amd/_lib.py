@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liboavif_hip.so")
+LIB_PATH = os.environ.get("OAVIF_AMD_LIB") or os.path.join(_HERE, "lib", "liboavif_hip.so")
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -19,6 +19,7 @@ ERR_HIP = -4
 ERR_NO_REFERENCE = -5
 ERR_NO_DEVICE = -6
 
+STAGE_PYRAMID, STAGE_MARCH, STAGE_FINALIZE = 0, 1, 2
 NUM_SCALES = 6
 STATS_PER_SCALE = 18
 TQ_MAX_PASS = 12
@@ -28,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ssimu2_ctx_create", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
     "ssimu2_set_reference", "ssimu2_score_against_reference", "ssimu2_score_rgb8_device",
     "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_time_device",
-    "ssimu2_time_scale_kernel",
+    "ssimu2_time_stage",
     "ssimu2_version",
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
@@ -100,8 +101,8 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_last_averages.restype = ci
     L.ssimu2_time_device.argtypes = [vp, vp, vp, u32, u32, ci, ctypes.POINTER(ctypes.c_float), f64p]
     L.ssimu2_time_device.restype = ci
-    L.ssimu2_time_scale_kernel.argtypes = [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)]
-    L.ssimu2_time_scale_kernel.restype = ci
+    L.ssimu2_time_stage.argtypes = [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)]
+    L.ssimu2_time_stage.restype = ci
     L.ssimu2_version.argtypes = []
     L.ssimu2_version.restype = ctypes.c_char_p
     L.oavif_tq_default_options.argtypes = [ctypes.POINTER(TQOptions)]

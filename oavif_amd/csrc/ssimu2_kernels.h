@@ -1,0 +1,568 @@
+// Device code of the MI355X (gfx950) SSIMULACRA2 scorer: included only by ssimu2_hip.hip.
+//
+// Kernels (wave64; VALU + LDS work, no MFMA: stencil and pointwise arithmetic):
+//   k_pyramid    : linear-light 2x2 box pyramid, up to three levels per launch from one read
+//                  of the input level (u8 sRGB frames through the LUT, or fp32 planes)
+//   k_march      : ONE launch for all scales: per workgroup, a strip of 120 output columns of
+//                  one scale is marched top to bottom: sRGB LUT -> opsin -> cbrt -> positive
+//                  XYB (converter waves, LDS ring of raw rows), horizontal 9-tap of
+//                  {x, y, xx, yy, xy} in registers, vertical 9-tap from a 9-row register
+//                  window, SSIM + edge-difference maps, fp64 partial sums
+//   k_finalize   : fixed-order fp64 reduction of the partials, 108 averages, weighted sum,
+//                  polynomial, score
+//
+// Arithmetic contract: this translation unit is compiled with -ffp-contract=off;
+// every fused multiply-add is an explicit fmaf().  The sequence of IEEE operations per pixel
+// is fixed and is the one the CPU checker evaluates, because the SSIM map cancels hard in
+// fp32 (a 1-ulp difference upstream moves the score by ~1e-3).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ssimu2_hip.h"
+
+namespace ssimu2 {
+
+constexpr int kNumScales = SSIMU2_NUM_SCALES;
+constexpr int kStats = SSIMU2_STATS_PER_SCALE;
+
+// ---- constants of the published algorithm (DESIGN.md "Algorithm") -----------------------------
+constexpr float kC2 = 0.0009f;
+constexpr float kM00 = 0.30f, kM01 = 0.622f, kM02 = 0.078f;
+constexpr float kM10 = 0.23f, kM11 = 0.692f, kM12 = 0.078f;
+constexpr float kM20 = 0.24342268924547819f, kM21 = 0.20476744424496821f,
+                kM22 = 0.55180986650955360f;
+constexpr float kOpsinBias = 0.0037930732552754493f;
+
+struct DevConst {
+    float lut[256];     // 8-bit sRGB -> linear, fp32(rounded from fp64)
+    float taps[5];      // FIR taps |d| = 0..4 of the sigma-1.5 recursive Gaussian
+    float cbrt_bias;    // cbrt_repro(kOpsinBias)
+    double weights[108];
+};
+__constant__ DevConst c_k;
+
+// ---- device helpers ---------------------------------------------------------------------------
+
+// Cube root from IEEE mul/fma only: bit-trick seed for x^(-1/3), two Newton steps,
+// c = x y^2, one residual-corrected Newton step on c.  Max error 0.76 ulp.
+__device__ __forceinline__ float cbrt_repro(float x) {
+    uint32_t i = __float_as_uint(x);
+    i = 0x54A2FA8Cu - i / 3u;
+    float y = __uint_as_float(i);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float t = x * y;
+        t = t * y;
+        t = t * y;
+        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
+    }
+    const float y2 = y * y;
+    float c = x * y2;
+    const float r = fmaf(c * c, c, -x);
+    c = fmaf(r, y2 * (-1.0f / 3.0f), c);
+    return x > 0.0f ? c : 0.0f;  // branch-free guard (inputs are clamped to >= 0)
+}
+
+__device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& X, float& Y,
+                                              float& B) {
+    float l = fmaf(kM00, r, fmaf(kM01, g, fmaf(kM02, b, kOpsinBias)));
+    float m = fmaf(kM10, r, fmaf(kM11, g, fmaf(kM12, b, kOpsinBias)));
+    float s = fmaf(kM20, r, fmaf(kM21, g, fmaf(kM22, b, kOpsinBias)));
+    l = fmaxf(l, 0.0f);
+    m = fmaxf(m, 0.0f);
+    s = fmaxf(s, 0.0f);
+    const float cb = c_k.cbrt_bias;
+    l = cbrt_repro(l) - cb;
+    m = cbrt_repro(m) - cb;
+    s = cbrt_repro(s) - cb;
+    const float x = 0.5f * (l - m), y = 0.5f * (l + m);
+    B = (s - y) + 0.55f;
+    X = fmaf(x, 14.0f, 0.42f);
+    Y = y + 0.01f;
+}
+
+// symmetric 9-tap in the contract's operation order: one mul, four FMAs.
+__device__ __forceinline__ float fir9(float c, float s1, float s2, float s3, float s4, float w0,
+                                      float w1, float w2, float w3, float w4) {
+    float acc = w0 * c;
+    acc = fmaf(w1, s1, acc);
+    acc = fmaf(w2, s2, acc);
+    acc = fmaf(w3, s3, acc);
+    acc = fmaf(w4, s4, acc);
+    return acc;
+}
+
+// Correctly rounded a / b for operands that need no exponent scaling (here b is in
+// [9e-4, 4], |a| < 4): v_rcp_f32 seed, one Newton step on the reciprocal, two fused
+// residual corrections of the quotient -- the sequence hipcc emits for `a / b` minus
+// v_div_scale / v_div_fixup, which only act on out-of-range exponents.  Same bits as the
+// IEEE division the CPU checker performs.
+__device__ __forceinline__ float div_rn(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = fmaf(-b, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = fmaf(-b, q, a);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-b, q, a);
+    return fmaf(e2, r, q);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- linear-light pyramid ----------------------------------------------------------------------
+// out(ox,oy) = (((p00 + p01) + p10) + p11) * 0.25 with coordinates clamped to the last
+// row/column of the level above (the published Downsample(in, 2, 2)).  One workgroup reads a
+// 64x64 tile of the input level once and emits the 32x32, 16x16 and 8x8 tiles of the next
+// three levels (tiles are aligned to powers of two, so every 2x2 source block, clamped or
+// not, lies inside the tile).  blockIdx.z selects the frame.
+struct PyramidArgs {
+    const void* in[2];   // per frame: u8 interleaved RGB (level 0) or fp32 planes [3][h][w]
+    float* out[2][3];    // per frame, per produced level: fp32 planes; null = not produced
+    int w[4], h[4];      // w[0],h[0] = input level; w[k],h[k] = k-th produced level
+    int nlevels;         // 1..3 levels to produce
+};
+
+template <bool kU8>
+__global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
+    __shared__ float s1[3][32][33];
+    __shared__ float s2[3][16][17];
+    __shared__ float s_lut[256];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.z;
+    if (kU8) s_lut[tid] = c_k.lut[tid];
+    if (kU8) __syncthreads();
+    const int w0 = a.w[0], h0 = a.h[0], w1 = a.w[1], h1 = a.h[1];
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;  // tile origin at level +1
+    const size_t n0 = (size_t)w0 * h0, n1 = (size_t)w1 * h1;
+    // level +1: 1024 outputs, 4 per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lx = tid & 31, ly = (tid >> 5) + 8 * j;
+        const int ox = tx0 + lx, oy = ty0 + ly;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (ox < w1 && oy < h1) {
+            const int xa = 2 * ox, xb = min(2 * ox + 1, w0 - 1);
+            const int ya = 2 * oy, yb = min(2 * oy + 1, h0 - 1);
+            if (kU8) {
+                const uint8_t* base = (const uint8_t*)a.in[f];
+                const uint8_t* p00 = base + ((size_t)ya * w0 + xa) * 3;
+                const uint8_t* p01 = base + ((size_t)ya * w0 + xb) * 3;
+                const uint8_t* p10 = base + ((size_t)yb * w0 + xa) * 3;
+                const uint8_t* p11 = base + ((size_t)yb * w0 + xb) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sum = s_lut[p00[c]];
+                    sum += s_lut[p01[c]];
+                    sum += s_lut[p10[c]];
+                    sum += s_lut[p11[c]];
+                    v[c] = sum * 0.25f;
+                }
+            } else {
+                const float* base = (const float*)a.in[f];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* p = base + c * n0;
+                    float sum = p[(size_t)ya * w0 + xa];
+                    sum += p[(size_t)ya * w0 + xb];
+                    sum += p[(size_t)yb * w0 + xa];
+                    sum += p[(size_t)yb * w0 + xb];
+                    v[c] = sum * 0.25f;
+                }
+            }
+            float* o = a.out[f][0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = v[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s1[c][ly][lx] = v[c];
+    }
+    if (a.nlevels < 2) return;
+    __syncthreads();
+    // level +2: 16x16 outputs, one per thread
+    const int w2 = a.w[2], h2 = a.h[2];
+    {
+        const int lx = tid & 15, ly = tid >> 4;
+        const int ox = (tx0 >> 1) + lx, oy = (ty0 >> 1) + ly;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (ox < w2 && oy < h2) {
+            // local coordinates inside s1; the clamp is against the level +1 image size
+            const int xa = 2 * lx, xb = min(2 * ox + 1, w1 - 1) - tx0;
+            const int ya = 2 * ly, yb = min(2 * oy + 1, h1 - 1) - ty0;
+            const size_t n2 = (size_t)w2 * h2;
+            float* o = a.out[f][1];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float sum = s1[c][ya][xa];
+                sum += s1[c][ya][xb];
+                sum += s1[c][yb][xa];
+                sum += s1[c][yb][xb];
+                v[c] = sum * 0.25f;
+                o[c * n2 + (size_t)oy * w2 + ox] = v[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s2[c][ly][lx] = v[c];
+    }
+    if (a.nlevels < 3) return;
+    __syncthreads();
+    // level +3: 8x8 outputs
+    if (tid < 64) {
+        const int w3 = a.w[3], h3 = a.h[3];
+        const int lx = tid & 7, ly = tid >> 3;
+        const int ox = (tx0 >> 2) + lx, oy = (ty0 >> 2) + ly;
+        if (ox < w3 && oy < h3) {
+            const int xa = 2 * lx, xb = min(2 * ox + 1, w2 - 1) - (tx0 >> 1);
+            const int ya = 2 * ly, yb = min(2 * oy + 1, h2 - 1) - (ty0 >> 1);
+            const size_t n3 = (size_t)w3 * h3;
+            float* o = a.out[f][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float sum = s2[c][ya][xa];
+                sum += s2[c][ya][xb];
+                sum += s2[c][yb][xa];
+                sum += s2[c][yb][xb];
+                o[c * n3 + (size_t)oy * w3 + ox] = sum * 0.25f;
+            }
+        }
+    }
+}
+
+// ---- fused per-scale kernel, marching form, all scales in one launch ----------------------------
+// One workgroup (10 waves) owns a strip of MW output columns of ONE scale and marches down
+// `seg` output rows, one image row per step.
+//   waves 0-3 (converters): lane = one staged column (MW + 8 halo = 128) of one frame.  Each
+//     step they convert one input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive XYB)
+//     into an LDS ring of raw rows, GROUP rows ahead of the blur waves; their global loads
+//     run PF more rows ahead, so HBM latency is off the critical path.
+//   waves 4-9 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
+//     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
+//     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
+//     registers and pushes the results into a 9-row register window, from which the
+//     vertical 9-tap and the SSIM / edge-difference maps of the row four steps back are
+//     evaluated and accumulated.  The row loop is unrolled nine times so the window is
+//     addressed with compile-time indices (no register moves).
+// One output pixel per lane keeps the window at 45 registers (<= 96 VGPRs, 5 waves/SIMD); a
+// lone wave issues a VALU op only every ~4 cycles, so occupancy is what fills the SIMDs.
+// The workgroup synchronises once per GROUP rows.
+// HBM traffic: each input pixel is read once per strip (+8/MW horizontal, +8/seg vertical
+// halo); only 18 partial sums per workgroup are written.
+// Scales are laid out largest first in the grid, so the short workgroups of the small scales
+// fill the tail of the big ones instead of running as five latency-bound launches.
+constexpr int RAD = 4;
+constexpr int MW = 120;        // output columns per strip
+constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 waves per frame
+constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
+constexpr int RING = 16;       // raw-row ring depth (power of two >= 10: rows t-4 .. t+5)
+constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
+constexpr int MARCH_THREADS = 640;
+constexpr int CONV_WAVES = 4;
+constexpr int PF = 4;          // rows the converters' global loads run ahead of the conversion
+
+struct MarchPlan {
+    int nscales;
+    int blk_end[kNumScales];   // exclusive end of each scale's block range in the grid
+    int w[kNumScales], h[kNumScales], seg[kNumScales], nstrips[kNumScales], nblocks[kNumScales];
+    const void* ref[kNumScales];   // scale 0: u8 interleaved; others: fp32 planes
+    const void* dist[kNumScales];
+    double* part[kNumScales];      // [18][nblocks] partial sums of the scale
+};
+
+// Raw values of one staged pixel of one frame of an input row (u8 codes or fp32 bits).
+struct MarchRaw {
+    uint32_t v[3];
+    bool ok;
+};
+
+// Issue the global loads of input row r, staged column `col` (global x = x0 - 4 + col).
+__device__ __forceinline__ void march_load(MarchRaw& raw, bool u8, const void* __restrict__ img,
+                                           int w, int h, int x0, int r, int col) {
+    const int gx = x0 - RAD + col;
+    raw.ok = r >= 0 && r < h && gx >= 0 && gx < w;
+    raw.v[0] = raw.v[1] = raw.v[2] = 0;
+    if (raw.ok) {
+        if (u8) {
+            const uint8_t* p = (const uint8_t*)img + ((size_t)r * w + gx) * 3;
+            raw.v[0] = p[0];
+            raw.v[1] = p[1];
+            raw.v[2] = p[2];
+        } else {
+            const size_t n = (size_t)w * h;
+            const uint32_t* p = (const uint32_t*)img + (size_t)r * w + gx;
+            raw.v[0] = p[0];
+            raw.v[1] = p[n];
+            raw.v[2] = p[2 * n];
+        }
+    }
+}
+
+// Convert the loaded pixel to positive XYB and store it into ring slot `slot` of frame k
+// (zeros outside the image: the blur is zero padded).
+__device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const float* lut, bool u8,
+                                              const MarchRaw& raw, int slot, int k, int col) {
+    float rr, gg, bb, v[3];
+    if (u8) {
+        rr = lut[raw.v[0]];
+        gg = lut[raw.v[1]];
+        bb = lut[raw.v[2]];
+    } else {
+        rr = __uint_as_float(raw.v[0]);
+        gg = __uint_as_float(raw.v[1]);
+        bb = __uint_as_float(raw.v[2]);
+    }
+#ifdef ABL_NOCONV
+    v[0] = rr; v[1] = gg; v[2] = bb;
+#else
+    linear_to_xyb(rr, gg, bb, v[0], v[1], v[2]);
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
+}
+
+template <int P>
+__device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&win)[5][9],
+                                              float (&acc)[6], int t, int ch, int o, bool ok,
+                                              float w0, float w1, float w2, float w3, float w4) {
+    const int slot = t & (RING - 1);
+    const float* px = &ring[slot][0][ch][o];  // staged columns o .. o+8, centre o+4
+    const float* py = &ring[slot][1][ch][o];
+    float xv[9], yv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        xv[q] = px[q];
+        yv[q] = py[q];
+    }
+#define H9(e) fir9(e(4), e(3) + e(5), e(2) + e(6), e(1) + e(7), e(0) + e(8), w0, w1, w2, w3, w4)
+#define EX(q) xv[q]
+#define EY(q) yv[q]
+#define EXX(q) (xv[q] * xv[q])
+#define EYY(q) (yv[q] * yv[q])
+#define EXY(q) (xv[q] * yv[q])
+    win[0][P] = H9(EX);
+    win[1][P] = H9(EY);
+    win[2][P] = H9(EXX);
+    win[3][P] = H9(EYY);
+    win[4][P] = H9(EXY);
+#undef EX
+#undef EY
+#undef EXX
+#undef EYY
+#undef EXY
+#undef H9
+#ifdef ABL_NOVMAPS
+    if (t >= 8) { acc[0] += win[0][(P + 5) % 9] + win[1][P] + win[2][P] + win[3][P] + win[4][P]; }
+    if (t < 0)
+#else
+    if (t >= 8)
+#endif
+    {  // window full (uniform across the workgroup)
+        // vertical 9-tap for the row four steps back: row t-j sits in window slot (P-j) mod 9
+        const int cslot = (t - 4) & (RING - 1);
+        const float r1 = ring[cslot][0][ch][o + RAD];
+        const float r2 = ring[cslot][1][ch][o + RAD];
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float* q = win[k];
+            v[k] = fir9(q[(P + 5) % 9], q[(P + 4) % 9] + q[(P + 6) % 9],
+                        q[(P + 3) % 9] + q[(P + 7) % 9], q[(P + 2) % 9] + q[(P + 8) % 9],
+                        q[(P + 1) % 9] + q[P], w0, w1, w2, w3, w4);
+        }
+        const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
+        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+        const float dm = mu1 - mu2;
+        const float num_m = fmaf(-dm, dm, 1.0f);
+        const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+        const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+        float d = 1.0f - div_rn(num_m * num_s, denom_s);
+        d = fmaxf(d, 0.0f);
+        const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+        float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
+        d = ok ? d : 0.0f;                      // column inside the image?
+        e = ok ? e : 0.0f;
+        const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
+        const float d2 = d * d, a2 = art * art, t2 = det * det;
+        acc[0] += d;
+        acc[1] += d2 * d2;
+        acc[2] += art;
+        acc[3] += a2 * a2;
+        acc[4] += det;
+        acc[5] += t2 * t2;
+    }
+}
+
+// Timing-only ablation switches (scripts/ablate.sh); never defined in the product build.
+#ifdef ABL_NOBARRIER
+#define MARCH_BARRIER() ((void)0)
+#else
+#define MARCH_BARRIER() __syncthreads()
+#endif
+
+__global__ __launch_bounds__(MARCH_THREADS) void k_march(MarchPlan plan) {
+    __shared__ __attribute__((aligned(16))) float s_ring[RING][2][3][MRW];
+    __shared__ float s_lut[256];
+    __shared__ double s_part[6][6];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // which scale / strip / segment is this workgroup?
+    int sc = 0, first = 0;
+#pragma unroll
+    for (int s = 0; s < kNumScales - 1; ++s)
+        if (s + 1 < plan.nscales && (int)blockIdx.x >= plan.blk_end[s]) {
+            sc = s + 1;
+            first = plan.blk_end[s];
+        }
+    const int blk = (int)blockIdx.x - first;
+    const int w = plan.w[sc], h = plan.h[sc], seg_rows = plan.seg[sc];
+    const int nstrips = plan.nstrips[sc];
+    const int by = blk / nstrips, bx = blk - by * nstrips;
+    const bool u8 = sc == 0;
+    const int x0 = bx * MW;
+    const int y0 = by * seg_rows;
+    const int rows_out = min(seg_rows, h - y0);
+    const int steps = rows_out + 2 * RAD;  // input rows y0-4 .. y0+rows_out+3
+    if (u8 && tid < 256) s_lut[tid] = c_k.lut[tid];
+    __syncthreads();
+
+    const float w0 = c_k.taps[0], w1 = c_k.taps[1], w2 = c_k.taps[2], w3 = c_k.taps[3],
+                w4 = c_k.taps[4];
+    const bool is_conv = wave < CONV_WAVES;
+    // (measured: raising the blur waves' issue priority with s_setprio makes the converters
+    // the laggards and costs 7 %; both roles run at default priority)
+    // converter state: wave -> (frame, half of the staged columns)
+    const int frame = wave >> 1;
+    const int col = ((wave & 1) << 6) + lane;
+    const void* img = frame ? plan.dist[sc] : plan.ref[sc];
+    MarchRaw q[PF], nxt;  // q[0] = next row to convert, q[PF-1] = newest loaded
+    // blur state (fp32 sums: at most seg <= 160 terms per lane before the fp64 reduce)
+    float win[5][9];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int hw = wave - CONV_WAVES;
+    const int ch = hw >> 1;
+    const bool hv_active = lane < MHALF;
+    const int o = (hw & 1) * MHALF + (hv_active ? lane : 0);
+    const bool ok = x0 + o < w;
+
+    // Input row j (= image row y0-4+j) lives in ring slot j & (RING-1).  While the blur waves
+    // consume rows 3I..3I+2 the converters fill rows 3I+3..3I+5.
+    if (is_conv) {
+        MarchRaw first_rows[GROUP];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j)
+            march_load(first_rows[j], u8, img, w, h, x0, y0 - RAD + j, col);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) march_load(q[j], u8, img, w, h, x0, y0 - RAD + GROUP + j, col);
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j)
+            march_convert(s_ring, s_lut, u8, first_rows[j], j, frame, col);
+    }
+    __syncthreads();
+
+#define MARCH_STEP(P)                                                                          \
+    {                                                                                          \
+        const int t = t0 + P;                                                                  \
+        if (t < steps) {                                                                       \
+            if (is_conv) {                                                                     \
+                if (t + GROUP < steps) {                                                       \
+                    march_load(nxt, u8, img, w, h, x0, y0 - RAD + t + GROUP + PF, col);        \
+                    march_convert(s_ring, s_lut, u8, q[0], (t + GROUP) & (RING - 1), frame,    \
+                                  col);                                                        \
+                    _Pragma("unroll") for (int j = 0; j + 1 < PF; ++j) q[j] = q[j + 1];        \
+                    q[PF - 1] = nxt;                                                           \
+                }                                                                              \
+            } else {                                                                           \
+                march_hv_step<P>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4);          \
+            }                                                                                  \
+        }                                                                                      \
+        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) MARCH_BARRIER();              \
+    }
+#pragma unroll 1
+    for (int t0 = 0; t0 < steps; t0 += 9) {
+        MARCH_STEP(0)
+        MARCH_STEP(1)
+        MARCH_STEP(2)
+        MARCH_STEP(3)
+        MARCH_STEP(4)
+        MARCH_STEP(5)
+        MARCH_STEP(6)
+        MARCH_STEP(7)
+        MARCH_STEP(8)
+    }
+#undef MARCH_STEP
+
+    // the two half-strip waves of a channel each publish their sums; combined in fixed order
+    if (!is_conv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double v = wave_sum(hv_active ? (double)acc[k] : 0.0);
+            if (lane == 0) s_part[hw][k] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < kStats) {
+        // tid = stat index: 0..5 ssim (c*2+n), 6..17 edge (c*4+k)
+        const int c = tid < 6 ? tid >> 1 : (tid - 6) >> 2;
+        const int k = tid < 6 ? (tid & 1) : 2 + ((tid - 6) & 3);
+        plan.part[sc][(size_t)tid * plan.nblocks[sc] + blk] = s_part[2 * c][k] + s_part[2 * c + 1][k];
+    }
+}
+
+// ---- final reduction ------------------------------------------------------------------------------
+struct FinalizeArgs {
+    const double* part[kNumScales];
+    int nblocks[kNumScales];
+    double inv_pixels[kNumScales];
+    int nscales;
+};
+
+// result layout: [0..107] averages [scale][18], [108] score, [109] nscales
+__global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __restrict__ result) {
+    __shared__ double s_avg[kNumScales * kStats];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int item = wave; item < kNumScales * kStats; item += 16) {
+        const int scale = item / kStats, stat = item - scale * kStats;
+        double v = 0.0;
+        if (scale < fa.nscales) {
+            const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
+            for (int b = lane; b < fa.nblocks[scale]; b += 64) v += p[b];
+            v = wave_sum(v);
+            v *= fa.inv_pixels[scale];
+            if (stat & 1) v = sqrt(sqrt(v));  // odd stats are L4 norms
+        }
+        if (lane == 0) {
+            s_avg[item] = v;
+            result[item] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // published Score(): running weight index over the scales actually present
+        double ssim = 0.0;
+        int i = 0;
+        for (int c = 0; c < 3; ++c)
+            for (int scale = 0; scale < fa.nscales; ++scale) {
+                const double* a = s_avg + scale * kStats;
+                for (int n = 0; n < 2; ++n) {
+                    ssim += c_k.weights[i++] * fabs(a[c * 2 + n]);
+                    ssim += c_k.weights[i++] * fabs(a[6 + c * 4 + n]);
+                    ssim += c_k.weights[i++] * fabs(a[6 + c * 4 + n + 2]);
+                }
+            }
+        ssim = ssim * 0.9562382616834844;
+        ssim = 2.326765642916932 * ssim - 0.020884521182843837 * ssim * ssim +
+               6.248496625763138e-05 * ssim * ssim * ssim;
+        if (ssim > 0.0) ssim = 100.0 - 10.0 * pow(ssim, 0.6276336467831387);
+        else ssim = 100.0;
+        result[108] = ssim;
+        result[109] = (double)fa.nscales;
+    }
+}
+
+}  // namespace ssimu2

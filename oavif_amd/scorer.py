@@ -129,12 +129,11 @@ class Ssimu2:
             self._raise(rc)
         return ms.value, out.value
 
-    def time_scale_kernel(self, d_ref: int, d_dist: int, w: int, h: int, scale: int, iters: int) -> float:
-        """-> average device ms of one launch of the fused kernel of `scale`."""
+    def time_stage(self, d_ref: int, d_dist: int, w: int, h: int, stage: int, iters: int) -> float:
+        """-> average device ms of one execution of `stage` (_lib.STAGE_*) of the score."""
         ms = ctypes.c_float()
-        rc = self._L.ssimu2_time_scale_kernel(self._ctx, ctypes.c_void_p(d_ref),
-                                              ctypes.c_void_p(d_dist), w, h, scale, iters,
-                                              ctypes.byref(ms))
+        rc = self._L.ssimu2_time_stage(self._ctx, ctypes.c_void_p(d_ref), ctypes.c_void_p(d_dist),
+                                       w, h, stage, iters, ctypes.byref(ms))
         if rc != 0:
             self._raise(rc)
         return ms.value

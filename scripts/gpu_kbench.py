@@ -12,7 +12,7 @@ torch.cuda.synchronize()
 s = oavif_amd.Ssimu2(0)
 score = s.score_device(tr.data_ptr(), td.data_ptr(), w, h)
 _, ns = s.last_averages()
-ks = [s.time_scale_kernel(tr.data_ptr(), td.data_ptr(), w, h, sc, 30) * 1e3 for sc in range(ns)]
+ks = [s.time_stage(tr.data_ptr(), td.data_ptr(), w, h, st, 30) * 1e3 for st in range(3)]
 ms, _ = s.time_device(tr.data_ptr(), td.data_ptr(), w, h, 50)
-tag = f"kernel={os.environ.get('OAVIF_AMD_KERNEL','march')} seg={os.environ.get('OAVIF_AMD_SEG_ROWS','auto')}"
-print(f"{tag}: score={score:.9f} scale_us={[round(k,1) for k in ks]} sum={sum(ks):.1f} whole_score_us={ms/50*1e3:.1f} MP/s={w*h/1e6/(ms/50/1e3):.0f}")
+tag = f"seg={os.environ.get('OAVIF_AMD_SEG_ROWS','auto')}"
+print(f"{tag}: score={score:.9f} stage_us[pyramid,march,finalize]={[round(k,1) for k in ks]} sum={sum(ks):.1f} whole_score_us={ms/50*1e3:.1f} MP/s={w*h/1e6/(ms/50/1e3):.0f}")
