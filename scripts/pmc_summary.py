@@ -4,7 +4,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            name = row["Kernel_Name"].split("(")[0][-40:]
+            name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][-48:]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name, ctrs in acc.items():
     print(name)
