@@ -1,0 +1,318 @@
+"""Batch driver: the MI355X-side counterpart of /root/reference/scripts/measure.py.
+
+measure.py runs the `oavif` binary once per image, one after another (measure.py:151-158).
+Here every rank of a `torch.distributed` job (one process per GPU) takes the images
+`rank, rank + world, ...` of the same sorted list (measure.py:137-140), runs the target-quality
+search for each (CPU libavif/aom encode + dav1d decode through Pillow, scorer on this rank's
+GPU), and the per-image result records are gathered to every rank with ONE all_gather
+(RCCL when the backend is nccl).  There is no data-path collective: images are independent.
+
+Kept from the reference: image selection (.png/.jpg/.jpeg, sorted), CSV header, column order
+and number formats (measure.py:178-206), the summary statistics (measure.py:209-269), the
+"--tolerance" / "--keep" flags, and main.zig's rule that the last probe's bytes are reused
+only when its quantizer is the chosen one (main.zig:109-113).
+
+    python -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV [--tolerance T] [--keep]
+    python -m torch.distributed.run --nproc-per-node 8 -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+import statistics
+import sys
+import time
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+IMAGE_EXTENSIONS = {".png", ".jpg", ".jpeg"}  # measure.py:136
+CSV_HEADER = ["Image", "Original Bytes", "Final Bytes", "Savings Bytes", "Savings %",
+              "Encoding Time (ms)", "Passes", "Status", "Error"]  # measure.py:181-191
+STATUS = ["ok", "no-output", "error"]
+RECORD_FIELDS = 8  # idx, status, q, score, passes, orig_bytes, final_bytes, time_ms
+
+
+@dataclass
+class ImageResult:
+    index: int
+    image: str
+    status: str = "ok"
+    q: int = 0
+    score: float = 0.0
+    passes: Optional[int] = None
+    orig_bytes: int = 0
+    final_bytes: Optional[int] = None
+    encoding_time_ms: Optional[float] = None
+    error: str = ""
+
+    @property
+    def savings_bytes(self) -> Optional[int]:
+        if self.final_bytes is None or self.orig_bytes == 0:
+            return None
+        return max(self.orig_bytes - self.final_bytes, 0)
+
+    @property
+    def savings_pct(self) -> Optional[float]:
+        s = self.savings_bytes
+        return None if s is None else s / self.orig_bytes * 100.0
+
+
+def list_images(images_dir) -> List[Path]:
+    d = Path(images_dir)
+    return sorted(f for f in d.iterdir() if f.is_file() and f.suffix.lower() in IMAGE_EXTENSIONS)
+
+
+def shard(n_items: int, rank: int, world: int) -> List[int]:
+    """Image i goes to rank i mod world."""
+    return list(range(rank, n_items, world))
+
+
+# ---- one image ---------------------------------------------------------------------------------
+
+def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float = 80.0,
+                 tolerance: float = 2.0, max_pass: int = 6, speed: int = 9):
+    """main.zig:73-116 for one file with the search on the GPU scorer.
+
+    Returns (q, score, passes, final_bytes)."""
+    from PIL import Image
+
+    from . import synth, tq
+    rgb = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB")))  # Image.toRGB8
+    cache = {}
+
+    def codec(q: int):
+        data = synth.avif_encode(rgb, q, speed)
+        cache.clear()
+        cache[q] = data                      # EncBuffer holds only the last probe (tq.zig:31-35)
+        return synth.avif_decode(data), len(data)
+
+    r = tq.search_hip(scorer, rgb, codec, score_tgt=score_tgt, tolerance=tolerance,
+                      max_pass=max_pass)
+    data = cache.get(r.q) if r.buf_q == r.q else None
+    if data is None:                         # main.zig:109-113: re-encode at the chosen q
+        data = synth.avif_encode(rgb, r.q, speed)
+    if out_path is not None:
+        out_path.write_bytes(data)
+    return r.q, r.score, r.num_pass, len(data)
+
+
+# ---- gather ----------------------------------------------------------------------------------------
+
+def pack_records(results: Sequence[ImageResult]) -> np.ndarray:
+    rec = np.zeros((len(results), RECORD_FIELDS), np.float64)
+    for i, r in enumerate(results):
+        rec[i] = [r.index, STATUS.index(r.status), r.q, r.score,
+                  -1 if r.passes is None else r.passes, r.orig_bytes,
+                  -1 if r.final_bytes is None else r.final_bytes,
+                  -1.0 if r.encoding_time_ms is None else r.encoding_time_ms]
+    return rec
+
+
+def gather_records(local: np.ndarray, n_total: int, device=None) -> np.ndarray:
+    """All-gather the (n_local, 8) float64 record arrays of all ranks -> (n_total, 8) sorted by
+    image index.  One collective; works on gloo (CPU tensors) and nccl = RCCL (GPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local[np.argsort(local[:, 0])] if len(local) else local
+    world = dist.get_world_size()
+    per_rank = (n_total + world - 1) // world
+    buf = torch.full((per_rank, RECORD_FIELDS), -2.0, dtype=torch.float64)
+    if len(local):
+        buf[: len(local)] = torch.from_numpy(local)
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    allrec = torch.cat(out).cpu().numpy()
+    allrec = allrec[allrec[:, 0] >= 0]
+    return allrec[np.argsort(allrec[:, 0])]
+
+
+# ---- CSV + summary (formats of measure.py:178-269) ---------------------------------------------------
+
+def records_to_results(rec: np.ndarray, names: Sequence[str], errors=None) -> List[ImageResult]:
+    out = []
+    for row in rec:
+        i = int(row[0])
+        out.append(ImageResult(
+            index=i, image=names[i], status=STATUS[int(row[1])], q=int(row[2]), score=float(row[3]),
+            passes=None if row[4] < 0 else int(row[4]), orig_bytes=int(row[5]),
+            final_bytes=None if row[6] < 0 else int(row[6]),
+            encoding_time_ms=None if row[7] < 0 else float(row[7]),
+            error=(errors or {}).get(i, "")))
+    return out
+
+
+def write_csv(path, results: Sequence[ImageResult]) -> None:
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(CSV_HEADER)
+        for m in results:
+            w.writerow([
+                m.image, m.orig_bytes,
+                m.final_bytes if m.final_bytes is not None else "",
+                m.savings_bytes if m.savings_bytes is not None else "",
+                f"{m.savings_pct:.2f}" if m.savings_pct is not None else "",
+                f"{m.encoding_time_ms:.2f}" if m.encoding_time_ms is not None else "",
+                m.passes if m.passes is not None else "",
+                m.status, m.error or ""])
+
+
+def human_bytes(n: float) -> str:
+    size = float(n)
+    for u in ("B", "KiB", "MiB", "GiB", "TiB"):
+        if size < 1024.0 or u == "TiB":
+            return f"{size:.2f} {u}"
+        size /= 1024.0
+    return f"{size:.2f} TiB"
+
+
+def summarize(results: Sequence[ImageResult], wall_s: float, world: int = 1) -> str:
+    ok = [m for m in results if m.status == "ok"]
+    errors = [m for m in results if m.status == "error"]
+    no_out = [m for m in results if m.status == "no-output"]
+    times = [m.encoding_time_ms for m in ok if m.encoding_time_ms is not None]
+    passes = [m.passes for m in ok if m.passes is not None]
+    orig_total = sum(m.orig_bytes for m in ok)
+    final_total = sum(m.final_bytes for m in ok if m.final_bytes is not None)
+    savings_total = max(orig_total - final_total, 0) if ok else 0
+    ratios = [m.final_bytes / m.orig_bytes for m in ok if m.final_bytes is not None and m.orig_bytes > 0]
+    lines = ["", "Run Summary",
+             f"Images: {len(ok)} ok, {len(no_out)} no-output, {len(errors)} errors",
+             f"Ranks (GPUs): {world}",
+             f"Total wall time: {wall_s:.2f} s",
+             f"Throughput: {(len(ok) / wall_s) if wall_s > 0 else 0.0:.2f} images/s",
+             f"Input bytes throughput: {human_bytes(orig_total / wall_s if wall_s > 0 else 0)}/s",
+             f"Output bytes throughput: {human_bytes(final_total / wall_s if wall_s > 0 else 0)}/s",
+             "", "Compression Totals",
+             f"Original total bytes: {orig_total} ({human_bytes(orig_total)})",
+             f"Final total bytes:    {final_total} ({human_bytes(final_total)})",
+             f"Savings (bytes):      {savings_total} ({human_bytes(savings_total)})",
+             f"% saved (overall):    {(savings_total / orig_total * 100.0) if orig_total else 0.0:.2f}%"]
+    if ratios:
+        try:
+            lines.append(f"% saved (geometric mean across files): "
+                         f"{(1.0 - statistics.geometric_mean(ratios)) * 100.0:.2f}%")
+        except ValueError:
+            pass
+    if times:
+        sd = statistics.stdev(times) if len(times) > 1 else 0.0
+        psd = statistics.stdev(passes) if len(passes) > 1 else 0.0
+        lines += ["", "Timing & Passes",
+                  f"Average encoding time: {sum(times) / len(times):.2f} ms ± {sd:.2f}",
+                  f"Median encoding time:  {statistics.median(times):.2f} ms",
+                  f"Average passes:        {(sum(passes) / len(passes)) if passes else 0.0:.2f} ± {psd:.2f} "
+                  f"(max: {max(passes) if passes else 0}, min: {min(passes) if passes else 0})"]
+    return "\n".join(lines)
+
+
+# ---- driver ----------------------------------------------------------------------------------------
+
+def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tuple], rank: int = 0,
+              world: int = 1, gather_device=None, log=None) -> List[ImageResult]:
+    """Process this rank's shard with `encode_fn(index, path) -> (q, score, passes, final_bytes)`
+    and return the gathered, index-sorted results of ALL ranks."""
+    local: List[ImageResult] = []
+    errors = {}
+    for i in shard(len(image_files), rank, world):
+        path = image_files[i]
+        res = ImageResult(index=i, image=path.name, orig_bytes=path.stat().st_size)
+        t0 = time.perf_counter()
+        try:
+            q, score, passes, final_bytes = encode_fn(i, path)
+            res.q, res.score, res.passes, res.final_bytes = int(q), float(score), int(passes), final_bytes
+            res.encoding_time_ms = (time.perf_counter() - t0) * 1000.0
+            res.status = "ok" if final_bytes is not None else "no-output"
+            if log:
+                # the reference's stderr contract (main.zig:106; parsed by measure.py:27)
+                log(f"[rank {rank}] {path.name}: Found q{res.q} (score {res.score:.2f}, {res.passes} passes)")
+        except Exception as e:  # measure.py:94-107: record and continue
+            res.status = "error"
+            res.error = f"Error processing {path}: {e}"
+            errors[i] = res.error
+            if log:
+                log(res.error)
+        local.append(res)
+    rec = gather_records(pack_records(local), len(image_files), gather_device)
+    names = [p.name for p in image_files]
+    results = records_to_results(rec, names)
+    for r in results:  # error strings stay on the rank that produced them; keep local ones
+        if r.index in errors:
+            r.error = errors[r.index]
+        elif r.status == "error":
+            r.error = "error on another rank (see its log)"
+    return results
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description="Target-quality AVIF encoding of a directory of images, "
+                                             "sharded over the GPUs of one node")
+    ap.add_argument("images_dir")
+    ap.add_argument("output_csv")
+    ap.add_argument("--tolerance", type=float, default=2.0)   # parse_args.zig:58
+    ap.add_argument("--score-tgt", type=float, default=80.0)  # parse_args.zig:55
+    ap.add_argument("--max-pass", type=int, default=6)        # parse_args.zig:59
+    ap.add_argument("--speed", type=int, default=9)           # parse_args.zig:50
+    ap.add_argument("--keep", action="store_true", help="keep the generated .avif files")
+    ap.add_argument("--out-dir", default="temp_avif_output")
+    args = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("oavif_amd.batch: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    files = list_images(args.images_dir)
+    if not files:
+        print(f"No images found in {args.images_dir}", file=sys.stderr)
+        return 1
+    out_dir = Path(args.out_dir)
+    out_dir.mkdir(exist_ok=True)
+
+    from . import Ssimu2
+    scorer = Ssimu2(local_rank)
+
+    def encode_fn(_i, path):
+        return encode_image(scorer, path, out_dir / f"{path.stem}.avif", args.score_tgt,
+                            args.tolerance, args.max_pass, args.speed)
+
+    if rank == 0:
+        print(f"Found {len(files)} images. Starting encoding on {world} GPU(s)...", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    results = run_batch(files, encode_fn, rank, world,
+                        gather_device=torch.device("cuda", local_rank) if world > 1 else None,
+                        log=lambda s: print(s, file=sys.stderr))
+    wall = time.perf_counter() - t0
+    if not args.keep:
+        for i in shard(len(files), rank, world):
+            try:
+                (out_dir / f"{files[i].stem}.avif").unlink()
+            except OSError:
+                pass
+    if rank == 0:
+        write_csv(args.output_csv, results)
+        print(summarize(results, wall, world))
+        print(f"\nResults written to {args.output_csv}")
+    scorer.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

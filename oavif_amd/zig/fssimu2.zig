@@ -1,0 +1,114 @@
+//! Drop-in `fssimu2` module for oavif that scores on an MI355X through liboavif_hip.so.
+//!
+//! oavif imports the scorer by module name and calls it at exactly one place:
+//!
+//!     src/tq.zig:3    const fssimu2 = @import("fssimu2");
+//!     src/tq.zig:37   return try fssimu2.computeSsimu2(allocator, e.rgb, decoded_rgb, e.w, e.h, 3, null);
+//!
+//! Point the "fssimu2" import of build.zig (build.zig:30-33,65) at this file and link
+//! liboavif_hip.so (INTEGRATION.md); src/tq.zig needs no edit.
+//!
+//! NOT COMPILED IN THIS REPO'S CI: the build container has no Zig toolchain.  The C ABI it
+//! binds (include/ssimu2_hip.h) is exercised by tests/ through ctypes instead.  The exact
+//! types of fssimu2 0.1.1's 6th and 7th parameters are not visible from the reference
+//! (its source is absent); they are declared here as what the call site passes: a
+//! comptime-known integer and `null`.
+
+const std = @import("std");
+
+pub const Error = error{
+    InvalidArgument, // SSIMU2_ERR_INVALID_ARG  (-1)
+    UnsupportedChannels, // SSIMU2_ERR_UNSUPPORTED (-2)
+    OutOfMemory, // SSIMU2_ERR_OOM          (-3)
+    HipFailure, // SSIMU2_ERR_HIP          (-4)
+    NoReference, // SSIMU2_ERR_NO_REFERENCE (-5)
+    NoDevice, // SSIMU2_ERR_NO_DEVICE    (-6)
+    Unknown,
+};
+
+const Ctx = opaque {};
+
+extern fn ssimu2_ctx_create(device: c_int, hip_stream: ?*anyopaque, out_ctx: *?*Ctx) c_int;
+extern fn ssimu2_ctx_destroy(ctx: ?*Ctx) void;
+extern fn ssimu2_last_error(ctx: ?*const Ctx) [*:0]const u8;
+extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: u32, h: u32, channels: u32, out_score: *f64) c_int;
+extern fn ssimu2_set_reference(ctx: ?*Ctx, ref: [*]const u8, w: u32, h: u32) c_int;
+extern fn ssimu2_score_against_reference(ctx: ?*Ctx, dist: [*]const u8, out_score: *f64) c_int;
+
+/// HIP device the process-wide scorer context binds to (set before the first call; the
+/// batch driver gives every worker process its own device).
+pub var device: c_int = 0;
+
+/// oavif scores every pass of a search against the same `e.rgb` slice (main.zig:86,
+/// tq.zig:37).  When true, a reference slice with the same pointer, length and dimensions
+/// as the previous call is uploaded (and its linear-light pyramid built) only once.
+/// Set to false if the caller mutates the reference buffer in place between calls.
+pub var cache_reference: bool = true;
+
+var g_ctx: ?*Ctx = null;
+var g_ref_ptr: ?[*]const u8 = null;
+var g_ref_len: usize = 0;
+var g_ref_w: u32 = 0;
+var g_ref_h: u32 = 0;
+
+fn check(rc: c_int) Error!void {
+    return switch (rc) {
+        0 => {},
+        -1 => Error.InvalidArgument,
+        -2 => Error.UnsupportedChannels,
+        -3 => Error.OutOfMemory,
+        -4 => Error.HipFailure,
+        -5 => Error.NoReference,
+        -6 => Error.NoDevice,
+        else => Error.Unknown,
+    };
+}
+
+fn context() Error!*Ctx {
+    if (g_ctx) |c| return c;
+    var c: ?*Ctx = null;
+    try check(ssimu2_ctx_create(device, null, &c));
+    g_ctx = c;
+    return c.?;
+}
+
+/// Release the GPU context (optional; the process exit does it too).
+pub fn deinit() void {
+    if (g_ctx) |c| ssimu2_ctx_destroy(c);
+    g_ctx = null;
+    g_ref_ptr = null;
+}
+
+/// Same call shape as fssimu2 0.1.1 as seen from tq.zig:37.  `allocator` is unused (device
+/// scratch lives in the context); `error_map` must be null (oavif passes null).
+pub fn computeSsimu2(
+    allocator: std.mem.Allocator,
+    reference: []const u8,
+    distorted: []const u8,
+    width: u32,
+    height: u32,
+    comptime channels: u32,
+    error_map: anytype,
+) Error!f64 {
+    _ = allocator;
+    _ = error_map;
+    const need: usize = @as(usize, width) * @as(usize, height) * channels;
+    if (reference.len < need or distorted.len < need) return Error.InvalidArgument;
+    const ctx = try context();
+    var score: f64 = 0;
+    if (cache_reference and channels == 3) {
+        const same = g_ref_ptr != null and g_ref_ptr.? == reference.ptr and
+            g_ref_len == reference.len and g_ref_w == width and g_ref_h == height;
+        if (!same) {
+            try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
+            g_ref_ptr = reference.ptr;
+            g_ref_len = reference.len;
+            g_ref_w = width;
+            g_ref_h = height;
+        }
+        try check(ssimu2_score_against_reference(ctx, distorted.ptr, &score));
+        return score;
+    }
+    try check(ssimu2_score_rgb8(ctx, reference.ptr, distorted.ptr, width, height, channels, &score));
+    return score;
+}

@@ -192,3 +192,29 @@ def test_4k_against_oracle(scorer, oracle):
     got = scorer.compute_ssimu2(ref, d)
     exp = oracle.compute_ssimu2(ref, d, oracle.BLUR_FIR, omp=True)
     assert abs(got - exp) <= TOL_SCORE
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+def test_batch_driver_single_rank(scorer, tmp_path):
+    """measure.py counterpart, one rank: real CPU codec, GPU scorer, CSV out."""
+    from PIL import Image
+    from oavif_amd import batch
+    for i in range(3):
+        Image.fromarray(synth.make_ref(160 + 16 * i, 128, 200 + i)).save(tmp_path / f"img{i}.png")
+    files = batch.list_images(tmp_path)
+    out = tmp_path / "out"
+    out.mkdir()
+
+    def enc(_i, path):
+        return batch.encode_image(scorer, path, out / f"{path.stem}.avif", 80.0, 2.0, 6, 9)
+    res = batch.run_batch(files, enc, 0, 1)
+    assert [r.status for r in res] == ["ok"] * 3
+    for r in res:
+        assert 1 <= r.passes <= 6 and 0 <= r.q <= 100
+        assert (out / f"{r.image[:-4]}.avif").stat().st_size == r.final_bytes
+        # the file on disk decodes and really has (about) the reported score
+        dec = synth.avif_decode((out / f"{r.image[:-4]}.avif").read_bytes())
+        ref = np.asarray(Image.open(tmp_path / r.image).convert("RGB"))
+        assert abs(scorer.compute_ssimu2(ref, dec) - r.score) < 1e-9
+    batch.write_csv(tmp_path / "o.csv", res)
+    assert (tmp_path / "o.csv").read_text().splitlines()[0].startswith("Image,Original Bytes")
