@@ -188,14 +188,14 @@ Pyramid make_pyramid(uint32_t w, uint32_t h) {
     return p;
 }
 
-// Rows per workgroup of the marching kernel.  Two 10-wave workgroups fit a CU, so 512
+// Rows per workgroup of the marching kernel.  Three 8-wave workgroups fit a CU, so 768
 // workgroups are one fully balanced resident round of the 256 CUs; aim at that for the
 // full-resolution scale, but keep a segment between 8 rows (vertical halo cost 8/seg) and
 // 160 rows (fp32 partial sums).
 int march_seg_rows(const ssimu2_ctx* c, int w, int h) {
     if (c->seg_rows_override > 0) return c->seg_rows_override;
     const int nstrips = (w + MW - 1) / MW;
-    int nsegs = (512 + nstrips / 2) / nstrips;
+    int nsegs = (768 + nstrips / 2) / nstrips;
     if (nsegs < 1) nsegs = 1;
     int seg = (h + nsegs - 1) / nsegs;
     if (seg < 8) seg = 8;

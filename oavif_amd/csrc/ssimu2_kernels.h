@@ -235,21 +235,22 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
 }
 
 // ---- fused per-scale kernel, marching form, all scales in one launch ----------------------------
-// One workgroup (10 waves) owns a strip of MW output columns of ONE scale and marches down
+// One workgroup (8 waves) owns a strip of MW output columns of ONE scale and marches down
 // `seg` output rows, one image row per step.
-//   waves 0-3 (converters): lane = one staged column (MW + 8 halo = 128) of one frame.  Each
+//   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128), both frames.  Each
 //     step they convert one input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive XYB)
-//     into an LDS ring of raw rows, GROUP rows ahead of the blur waves; their global loads
-//     run PF more rows ahead, so HBM latency is off the critical path.
-//   waves 4-9 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
+//     into an LDS ring of raw rows, two barrier groups ahead of the blur waves; their global
+//     loads run PF more rows ahead, so HBM latency is off the critical path.
+//   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
 //     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
 //     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
 //     registers and pushes the results into a 9-row register window, from which the
 //     vertical 9-tap and the SSIM / edge-difference maps of the row four steps back are
 //     evaluated and accumulated.  The row loop is unrolled nine times so the window is
 //     addressed with compile-time indices (no register moves).
-// One output pixel per lane keeps the window at 45 registers (<= 96 VGPRs, 5 waves/SIMD); a
-// lone wave issues a VALU op only every ~4 cycles, so occupancy is what fills the SIMDs.
+// One output pixel per lane keeps the window at 45 registers, and the two roles run separate
+// loops (own register allocation): <= 80 VGPRs, 3 workgroups = 24 waves per CU.  A lone wave
+// issues a VALU op only every ~4 cycles, so occupancy is what fills the SIMDs.
 // The workgroup synchronises once per GROUP rows.
 // HBM traffic: each input pixel is read once per strip (+8/MW horizontal, +8/seg vertical
 // halo); only 18 partial sums per workgroup are written.
@@ -259,10 +260,11 @@ constexpr int RAD = 4;
 constexpr int MW = 120;        // output columns per strip
 constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 waves per frame
 constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
-constexpr int RING = 16;       // raw-row ring depth (power of two >= 10: rows t-4 .. t+5)
+constexpr int RING = 16;       // raw-row ring depth (power of two >= 13: rows t-4 .. t+8)
+constexpr int AHEAD = 2 * 3;   // rows the converters run ahead of the blur waves (2 groups)
 constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
-constexpr int MARCH_THREADS = 640;
-constexpr int CONV_WAVES = 4;
+constexpr int MARCH_THREADS = 512;
+constexpr int CONV_WAVES = 2;  // each converter lane handles one staged column of BOTH frames
 constexpr int PF = 4;          // rows the converters' global loads run ahead of the conversion
 
 struct MarchPlan {
@@ -325,25 +327,39 @@ __device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const fl
     for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
 }
 
+// LDS reads of one blur-wave step: the 9-wide x / y windows of ring row t and the centre pixel
+// of the output row (t - 4).  Issued one step ahead of their use (see march_hv_step).
+struct MarchTaps {
+    float x[9], y[9], r1, r2;
+};
+
+__device__ __forceinline__ void march_hv_fetch(MarchTaps& m, float (*ring)[2][3][MRW], int t, int ch,
+                                               int o) {
+    const int slot = t & (RING - 1);
+    const float* px = &ring[slot][0][ch][o];  // staged columns o .. o+8, centre o+4
+    const float* py = &ring[slot][1][ch][o];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        m.x[q] = px[q];
+        m.y[q] = py[q];
+    }
+    const int cslot = (t - 4) & (RING - 1);
+    m.r1 = ring[cslot][0][ch][o + RAD];
+    m.r2 = ring[cslot][1][ch][o + RAD];
+}
+
 template <int P>
 __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&win)[5][9],
                                               float (&acc)[6], int t, int ch, int o, bool ok,
                                               float w0, float w1, float w2, float w3, float w4) {
-    const int slot = t & (RING - 1);
-    const float* px = &ring[slot][0][ch][o];  // staged columns o .. o+8, centre o+4
-    const float* py = &ring[slot][1][ch][o];
-    float xv[9], yv[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        xv[q] = px[q];
-        yv[q] = py[q];
-    }
+    MarchTaps cur;
+    march_hv_fetch(cur, ring, t, ch, o);
 #define H9(e) fir9(e(4), e(3) + e(5), e(2) + e(6), e(1) + e(7), e(0) + e(8), w0, w1, w2, w3, w4)
-#define EX(q) xv[q]
-#define EY(q) yv[q]
-#define EXX(q) (xv[q] * xv[q])
-#define EYY(q) (yv[q] * yv[q])
-#define EXY(q) (xv[q] * yv[q])
+#define EX(q) cur.x[q]
+#define EY(q) cur.y[q]
+#define EXX(q) (cur.x[q] * cur.x[q])
+#define EYY(q) (cur.y[q] * cur.y[q])
+#define EXY(q) (cur.x[q] * cur.y[q])
     win[0][P] = H9(EX);
     win[1][P] = H9(EY);
     win[2][P] = H9(EXX);
@@ -355,6 +371,7 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
 #undef EYY
 #undef EXY
 #undef H9
+    const float r1 = cur.r1, r2 = cur.r2;
 #ifdef ABL_NOVMAPS
     if (t >= 8) { acc[0] += win[0][(P + 5) % 9] + win[1][P] + win[2][P] + win[3][P] + win[4][P]; }
     if (t < 0)
@@ -363,9 +380,6 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
 #endif
     {  // window full (uniform across the workgroup)
         // vertical 9-tap for the row four steps back: row t-j sits in window slot (P-j) mod 9
-        const int cslot = (t - 4) & (RING - 1);
-        const float r1 = ring[cslot][0][ch][o + RAD];
-        const float r2 = ring[cslot][1][ch][o + RAD];
         float v[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -404,7 +418,8 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
 #define MARCH_BARRIER() __syncthreads()
 #endif
 
-__global__ __launch_bounds__(MARCH_THREADS) void k_march(MarchPlan plan) {
+// launch bound: 3 workgroups of 8 waves per CU = 6 waves per SIMD (<= 80 VGPRs)
+__global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     __shared__ __attribute__((aligned(16))) float s_ring[RING][2][3][MRW];
     __shared__ float s_lut[256];
     __shared__ double s_part[6][6];
@@ -436,13 +451,7 @@ __global__ __launch_bounds__(MARCH_THREADS) void k_march(MarchPlan plan) {
     const bool is_conv = wave < CONV_WAVES;
     // (measured: raising the blur waves' issue priority with s_setprio makes the converters
     // the laggards and costs 7 %; both roles run at default priority)
-    // converter state: wave -> (frame, half of the staged columns)
-    const int frame = wave >> 1;
-    const int col = ((wave & 1) << 6) + lane;
-    const void* img = frame ? plan.dist[sc] : plan.ref[sc];
-    MarchRaw q[PF], nxt;  // q[0] = next row to convert, q[PF-1] = newest loaded
     // blur state (fp32 sums: at most seg <= 160 terms per lane before the fp64 reduce)
-    float win[5][9];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int hw = wave - CONV_WAVES;
     const int ch = hw >> 1;
@@ -451,51 +460,78 @@ __global__ __launch_bounds__(MARCH_THREADS) void k_march(MarchPlan plan) {
     const bool ok = x0 + o < w;
 
     // Input row j (= image row y0-4+j) lives in ring slot j & (RING-1).  While the blur waves
-    // consume rows 3I..3I+2 the converters fill rows 3I+3..3I+5.
+    // consume rows 3I..3I+2 the converters fill rows 3I+6..3I+8 (two groups ahead, so a blur
+    // wave may read one row past its group).  The two roles run separate loops with the same
+    // number of barriers (one per group of GROUP rows), so each gets its own register
+    // allocation instead of carrying the other role's state.
+    const int ngroups = (steps + GROUP - 1) / GROUP;
     if (is_conv) {
-        MarchRaw first_rows[GROUP];
+        const int col = (wave << 6) + lane;  // staged column; this lane converts both frames
+        MarchRaw q[2][PF], nxt[2];  // per frame: q[0] = next row to convert, q[PF-1] = newest
 #pragma unroll
-        for (int j = 0; j < GROUP; ++j)
-            march_load(first_rows[j], u8, img, w, h, x0, y0 - RAD + j, col);
+        for (int j0 = 0; j0 < AHEAD; j0 += GROUP) {
+            MarchRaw first_rows[2][GROUP];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) march_load(q[j], u8, img, w, h, x0, y0 - RAD + GROUP + j, col);
+            for (int j = 0; j < GROUP; ++j) {
+                march_load(first_rows[0][j], u8, plan.ref[sc], w, h, x0, y0 - RAD + j0 + j, col);
+                march_load(first_rows[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + j0 + j, col);
+            }
 #pragma unroll
-        for (int j = 0; j < GROUP; ++j)
-            march_convert(s_ring, s_lut, u8, first_rows[j], j, frame, col);
-    }
-    __syncthreads();
-
-#define MARCH_STEP(P)                                                                          \
-    {                                                                                          \
-        const int t = t0 + P;                                                                  \
-        if (t < steps) {                                                                       \
-            if (is_conv) {                                                                     \
-                if (t + GROUP < steps) {                                                       \
-                    march_load(nxt, u8, img, w, h, x0, y0 - RAD + t + GROUP + PF, col);        \
-                    march_convert(s_ring, s_lut, u8, q[0], (t + GROUP) & (RING - 1), frame,    \
-                                  col);                                                        \
-                    _Pragma("unroll") for (int j = 0; j + 1 < PF; ++j) q[j] = q[j + 1];        \
-                    q[PF - 1] = nxt;                                                           \
-                }                                                                              \
-            } else {                                                                           \
-                march_hv_step<P>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4);          \
-            }                                                                                  \
-        }                                                                                      \
-        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) MARCH_BARRIER();              \
+            for (int j = 0; j < GROUP; ++j) {
+                march_convert(s_ring, s_lut, u8, first_rows[0][j], j0 + j, 0, col);
+                march_convert(s_ring, s_lut, u8, first_rows[1][j], j0 + j, 1, col);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            march_load(q[0][j], u8, plan.ref[sc], w, h, x0, y0 - RAD + AHEAD + j, col);
+            march_load(q[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + AHEAD + j, col);
+        }
+        MARCH_BARRIER();
+#pragma unroll 1
+        for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+            for (int j = 0; j < GROUP; ++j) {
+                const int r = g * GROUP + j + AHEAD;  // ring row to produce
+                if (r < steps) {
+                    march_load(nxt[0], u8, plan.ref[sc], w, h, x0, y0 - RAD + r + PF, col);
+                    march_load(nxt[1], u8, plan.dist[sc], w, h, x0, y0 - RAD + r + PF, col);
+                    march_convert(s_ring, s_lut, u8, q[0][0], r & (RING - 1), 0, col);
+                    march_convert(s_ring, s_lut, u8, q[1][0], r & (RING - 1), 1, col);
+#pragma unroll
+                    for (int k = 0; k + 1 < PF; ++k) {
+                        q[0][k] = q[0][k + 1];
+                        q[1][k] = q[1][k + 1];
+                    }
+                    q[0][PF - 1] = nxt[0];
+                    q[1][PF - 1] = nxt[1];
+                }
+            }
+            MARCH_BARRIER();
+        }
+    } else {
+        float win[5][9];
+        MARCH_BARRIER();
+#define MARCH_STEP(P)                                                                     \
+    {                                                                                     \
+        const int t = t0 + P;                                                             \
+        if (t < steps) march_hv_step<P>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4); \
+        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) MARCH_BARRIER();         \
     }
 #pragma unroll 1
-    for (int t0 = 0; t0 < steps; t0 += 9) {
-        MARCH_STEP(0)
-        MARCH_STEP(1)
-        MARCH_STEP(2)
-        MARCH_STEP(3)
-        MARCH_STEP(4)
-        MARCH_STEP(5)
-        MARCH_STEP(6)
-        MARCH_STEP(7)
-        MARCH_STEP(8)
-    }
+        for (int t0 = 0; t0 < steps; t0 += 9) {
+            MARCH_STEP(0)
+            MARCH_STEP(1)
+            MARCH_STEP(2)
+            MARCH_STEP(3)
+            MARCH_STEP(4)
+            MARCH_STEP(5)
+            MARCH_STEP(6)
+            MARCH_STEP(7)
+            MARCH_STEP(8)
+        }
 #undef MARCH_STEP
+    }
 
     // the two half-strip waves of a channel each publish their sums; combined in fixed order
     if (!is_conv) {
