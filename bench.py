@@ -52,6 +52,8 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent scorer contexts (HIP streams) the steps are dealt over")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
@@ -90,7 +92,13 @@ def main() -> int:
     assert t_ref.is_contiguous() and t_dst.is_contiguous()
     torch.cuda.synchronize()
 
-    scorer = oavif_amd.Ssimu2(local_rank)
+    # Steps are independent scores (independent images / quantizer probes); they are dealt
+    # round-robin over a few scorer contexts, each with its own HIP stream and scratch, so the
+    # HBM-bound pyramid kernel and the latency-bound final reduction of one score overlap the
+    # VALU-bound marching kernel of another.  Every step is still one full score.
+    nctx = max(1, args.streams)
+    scorers = [oavif_amd.Ssimu2(local_rank) for _ in range(nctx)]
+    scorer = scorers[0]
     p_ref, p_dst = t_ref.data_ptr(), t_dst.data_ptr()
 
     def barrier():
@@ -98,17 +106,23 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_steps(n):
+        used = set()
+        for i in range(n):
+            scorers[i % nctx].enqueue_device(p_ref, p_dst, w, h)
+            used.add(i % nctx)
+        sc = None
+        for j in sorted(used):
+            sc = scorers[j].wait()     # drains that context's stream
+        return sc
+
     score = None
-    for _ in range(args.warmup):
-        scorer.enqueue_device(p_ref, p_dst, w, h)
     if args.warmup:
-        score = scorer.wait()
+        score = run_steps(args.warmup)
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scorer.enqueue_device(p_ref, p_dst, w, h)
-    score = scorer.wait()          # drains the ctx stream (all K scores)
+    score = run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -143,6 +157,7 @@ def main() -> int:
                                    f"step per GPU, inputs resident in HBM (BASELINE configs[1])",
                        "width": w, "height": h, "pairs_per_step": world,
                        "parallelism": f"image-per-gpu x{world}" if world > 1 else "single gpu",
+                       "streams_per_gpu": nctx,
                        "kernels": oavif_amd.version()},
             "scores": [round(s, 6) for s in scores],
         }
@@ -220,7 +235,8 @@ def main() -> int:
                 "score_abs_diff_vs_hip": abs(cpu_score - scores[0])}
         print(json.dumps(out), flush=True)
 
-    scorer.close()
+    for sc_ in scorers:
+        sc_.close()
     if distributed:
         dist.destroy_process_group()
     return 0

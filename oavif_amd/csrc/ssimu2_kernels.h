@@ -559,23 +559,28 @@ struct FinalizeArgs {
 };
 
 // result layout: [0..107] averages [scale][18], [108] score, [109] nscales
+// 8 lanes per (scale, stat) item stride over the workgroup partials; lane-local sums, then a
+// fixed-order 8-lane shuffle tree: deterministic, and 128 items run in parallel instead of 16.
 __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __restrict__ result) {
     __shared__ double s_avg[kNumScales * kStats];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int item = wave; item < kNumScales * kStats; item += 16) {
-        const int scale = item / kStats, stat = item - scale * kStats;
-        double v = 0.0;
-        if (scale < fa.nscales) {
-            const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
-            for (int b = lane; b < fa.nblocks[scale]; b += 64) v += p[b];
-            v = wave_sum(v);
+    const int item = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    double v = 0.0;
+    const int scale = item / kStats, stat = item - scale * kStats;
+    const bool live = item < kNumScales * kStats && scale < fa.nscales;
+    if (live) {
+        const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
+        for (int b = sub; b < fa.nblocks[scale]; b += 8) v += p[b];
+    }
+    v += __shfl_down(v, 4, 8);
+    v += __shfl_down(v, 2, 8);
+    v += __shfl_down(v, 1, 8);
+    if (sub == 0 && item < kNumScales * kStats) {
+        if (live) {
             v *= fa.inv_pixels[scale];
             if (stat & 1) v = sqrt(sqrt(v));  // odd stats are L4 norms
         }
-        if (lane == 0) {
-            s_avg[item] = v;
-            result[item] = v;
-        }
+        s_avg[item] = v;
+        result[item] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -583,8 +588,8 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __re
         double ssim = 0.0;
         int i = 0;
         for (int c = 0; c < 3; ++c)
-            for (int scale = 0; scale < fa.nscales; ++scale) {
-                const double* a = s_avg + scale * kStats;
+            for (int sc = 0; sc < fa.nscales; ++sc) {
+                const double* a = s_avg + sc * kStats;
                 for (int n = 0; n < 2; ++n) {
                     ssim += c_k.weights[i++] * fabs(a[c * 2 + n]);
                     ssim += c_k.weights[i++] * fabs(a[6 + c * 4 + n]);
