@@ -150,5 +150,26 @@ class Ssimu2:
         return avg.reshape(_lib.NUM_SCALES, _lib.STATS_PER_SCALE), ns.value
 
 
+def score_many(scorers, d_ref: int, d_dists, w: int, h: int):
+    """Score several distorted frames against one reference, fanned over `scorers`
+    (independent contexts = independent HIP streams on one or more GPUs).  All pointers are
+    device addresses valid on each scorer's device.  Returns the scores in input order; each is
+    bit-identical to scoring that frame alone (a context never shares state with another).
+
+    This is the mechanism for speculative quantizer probes: the decoded frames
+    of several candidate quantizers are scored concurrently, then tq replays its sequential
+    decision logic over the cached scores.
+    """
+    out = [None] * len(d_dists)
+    n = len(scorers)
+    for base in range(0, len(d_dists), n):
+        batch = list(range(base, min(base + n, len(d_dists))))
+        for j, i in enumerate(batch):
+            scorers[j].enqueue_device(d_ref, d_dists[i], w, h)
+        for j, i in enumerate(batch):
+            out[i] = scorers[j].wait()
+    return out
+
+
 def version() -> str:
     return _lib.lib().ssimu2_version().decode()

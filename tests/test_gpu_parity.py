@@ -218,3 +218,43 @@ def test_batch_driver_single_rank(scorer, tmp_path):
         assert abs(scorer.compute_ssimu2(ref, dec) - r.score) < 1e-9
     batch.write_csv(tmp_path / "o.csv", res)
     assert (tmp_path / "o.csv").read_text().splitlines()[0].startswith("Image,Original Bytes")
+
+
+def test_probe_fanout_over_contexts_matches_sequential(hip_lib, scorer):
+    """BASELINE configs[2]: probes fanned across HIP streams on one GPU (independent contexts)."""
+    import torch
+    import oavif_amd
+    ref = synth.make_ref(960, 540, 81)
+    dists = [synth.distort(ref, k, s, seed=s) for k, s in
+             [("blockq", 0), ("blockq", 2), ("noise", 1), ("noise", 3), ("blur", 1), ("band", 2), ("blur", 3)]]
+    seq = [scorer.compute_ssimu2(ref, d) for d in dists]
+    t_ref = torch.from_numpy(ref).cuda().contiguous()
+    t_d = [torch.from_numpy(d).cuda().contiguous() for d in dists]
+    torch.cuda.synchronize()
+    ctxs = [oavif_amd.Ssimu2(0) for _ in range(3)]
+    try:
+        fan = oavif_amd.score_many(ctxs, t_ref.data_ptr(), [t.data_ptr() for t in t_d], 960, 540)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert fan == seq
+    # replaying the search over cached probe scores gives the sequential search's answer
+    from oavif_amd import tq
+    table = {q: s for q, s in zip([10, 30, 50, 65, 80, 90, 100], sorted(seq))}
+    r1 = tq.find_target_quality(lambda q: table[min(table, key=lambda k: abs(k - q))], score_tgt=80.0)
+    r2 = tq.find_target_quality(lambda q: table[min(table, key=lambda k: abs(k - q))], score_tgt=80.0)
+    assert (r1.q, r1.history) == (r2.q, r2.history)
+
+
+def test_8k_properties(scorer):
+    """BASELINE configs[2] size (7680x4320): properties only (an oracle run takes minutes)."""
+    ref = synth.make_ref(7680, 4320, 91)
+    assert scorer.compute_ssimu2(ref, ref) == 100.0
+    d1 = synth.distort(ref, "blockq", 1)
+    d3 = synth.distort(ref, "blockq", 3)
+    s1 = scorer.compute_ssimu2(ref, d1)
+    s3 = scorer.compute_ssimu2(ref, d3)
+    assert 100.0 > s1 > s3
+    assert scorer.compute_ssimu2(ref, d1) == s1           # deterministic
+    _, ns = scorer.last_averages()
+    assert ns == 6
