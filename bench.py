@@ -195,6 +195,25 @@ def main() -> int:
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ALGO_BYTES_PER_PX_SCORE * w * h / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+        # ---- the search's per-pass score: reference cached on the device (tq.zig:37 passes the
+        # same e.rgb every pass), distorted frame already in HBM -------------------------------
+        scorer.set_reference_device(p_ref, w, h)
+        for _ in range(10):
+            scorer.enqueue_against_reference_device(p_dst)
+        scorer.wait()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        n_c = 100
+        for _ in range(n_c):
+            scorer.enqueue_against_reference_device(p_dst)
+        c_score = scorer.wait()
+        torch.cuda.synchronize()
+        c_ms = (time.perf_counter() - tt) / n_c * 1e3
+        out["cached_reference"] = {"ms_per_score": round(c_ms, 5), "MP_per_s": round(mp / c_ms * 1e3, 1),
+                                   "bit_identical_to_pair_score": bool(c_score == scores[0]),
+                                   "note": "reference XYB + pyramid cached by ssimu2_set_reference; "
+                                           "one stream; separate from `value`"}
+
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
         scorer.set_reference(ref)
         scorer.score_against_reference(dst)

@@ -69,7 +69,9 @@ int ssimu2_score_rgb8(ssimu2_ctx* ctx, const uint8_t* ref, const uint8_t* dist, 
 /* The search scores many `dist` frames against one fixed `ref` (tq.zig:37 passes the same
    e.rgb on every pass, main.zig:86).  set_reference uploads `ref` once and keeps only
    device copies (its linear-light pyramid); score_against_reference then uploads and
-   scores one `dist`.  Results are bit-identical to ssimu2_score_rgb8 on the same pair. */
+   scores one `dist`.  Besides the linear-light pyramid, the reference's positive-XYB planes
+   are cached at every scale, so each pass skips the colour conversion of the reference frame.
+   Results are bit-identical to ssimu2_score_rgb8 on the same pair. */
 int ssimu2_set_reference(ssimu2_ctx* ctx, const uint8_t* ref, uint32_t w, uint32_t h);
 int ssimu2_score_against_reference(ssimu2_ctx* ctx, const uint8_t* dist, double* out_score);
 
@@ -83,6 +85,13 @@ int ssimu2_score_rgb8_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_d
 int ssimu2_enqueue_rgb8_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist,
                                uint32_t w, uint32_t h);
 int ssimu2_wait(ssimu2_ctx* ctx, double* out_score);
+
+/* Reference-cached scoring with device-resident frames: set_reference_device copies `d_ref`
+   (device pointer, RGB8 layout) into the ctx and builds the same caches as
+   ssimu2_set_reference; enqueue_against_reference_device scores one device-resident `d_dist`
+   against it without blocking (finish with ssimu2_wait). */
+int ssimu2_set_reference_device(ssimu2_ctx* ctx, const void* d_ref, uint32_t w, uint32_t h);
+int ssimu2_enqueue_against_reference_device(ssimu2_ctx* ctx, const void* d_dist);
 
 /* The 108 plane averages behind the last finished score, [scale][18] with
    18 = 6 SSIM (channel*2 + {L1,L4}) then 12 edge (channel*4 + {art L1, art L4, det L1,

@@ -129,6 +129,8 @@ struct ssimu2_ctx {
     uint8_t* d_dist_u8 = nullptr;
     float* d_lin_ref = nullptr;   // scales 1..5 packed
     float* d_lin_dist = nullptr;
+    float* d_xyb_ref = nullptr;   // cached positive-XYB planes of the reference, all scales
+    size_t cap_xyb = 0;
     double* d_partials = nullptr;
     double* d_result = nullptr;   // 110 doubles
     double* h_result = nullptr;   // pinned mirror
@@ -220,6 +222,9 @@ void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_lin_ref);
     (void)hipFree(c->d_lin_dist);
     (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_xyb_ref);
+    c->d_xyb_ref = nullptr;
+    c->cap_xyb = 0;
     c->d_ref_u8 = c->d_dist_u8 = nullptr;
     c->d_lin_ref = c->d_lin_dist = nullptr;
     c->d_partials = nullptr;
@@ -276,8 +281,15 @@ void launch_pyramid(ssimu2_ctx* c, const Pyramid& p, int nframes, const uint8_t*
     }
 }
 
+// float offset of scale s in the cached reference XYB buffer (scale 0 first)
+size_t xyb_off(const Pyramid& p, int s) {
+    size_t off = 0;
+    for (int k = 0; k < s; ++k) off += (size_t)3 * p.w[k] * p.h[k];
+    return off;
+}
+
 void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, const uint8_t* d_dist,
-                 MarchPlan* mp, FinalizeArgs* fa, int* total_blocks) {
+                 bool ref_xyb_cached, MarchPlan* mp, FinalizeArgs* fa, int* total_blocks) {
     memset(mp, 0, sizeof *mp);
     memset(fa, 0, sizeof *fa);
     mp->nscales = fa->nscales = p.nscales;
@@ -296,6 +308,7 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
         mp->nblocks[s] = nb;
         mp->ref[s] = s == 0 ? (const void*)d_ref : (const void*)(c->d_lin_ref + p.lin_off[s]);
         mp->dist[s] = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
+        mp->ref_xyb[s] = ref_xyb_cached ? c->d_xyb_ref + xyb_off(p, s) : nullptr;
         mp->part[s] = c->d_partials + poff;
         fa->part[s] = mp->part[s];
         fa->nblocks[s] = nb;
@@ -324,7 +337,7 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
     MarchPlan mp;
     FinalizeArgs fa;
     int blocks = 0;
-    build_plans(c, p, d_ref, d_dist, &mp, &fa, &blocks);
+    build_plans(c, p, d_ref, d_dist, ref_pyramid_ready && c->d_xyb_ref != nullptr, &mp, &fa, &blocks);
     if (blocks > 0)
         hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
@@ -466,18 +479,43 @@ int ssimu2_score_rgb8(ssimu2_ctx* c, const uint8_t* ref, const uint8_t* dist, ui
     return ssimu2_wait(c, out_score);
 }
 
-int ssimu2_set_reference(ssimu2_ctx* c, const uint8_t* ref, uint32_t w, uint32_t h) {
+static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32_t h,
+                              hipMemcpyKind kind) {
     int rc = check_args(c, ref, ref, w, h);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_capacity(c, w, h))) return rc;
     const size_t bytes = (size_t)w * h * 3;
-    HIP_TRY(c, hipMemcpyAsync(c->d_ref_u8, ref, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ref_u8, ref, bytes, kind, c->stream));
     const Pyramid p = make_pyramid(w, h);
     if (p.nscales > 1) {  // the reference's linear pyramid, once per search
         const uint8_t* frames[1] = {c->d_ref_u8};
         float* lin[1] = {c->d_lin_ref};
         launch_pyramid(c, p, 1, frames, lin);
+    }
+    // ... and its positive-XYB planes at every scale, so that the per-pass kernel skips the
+    // LUT / opsin / cube-root work for the reference frame (same values, bit-identical scores)
+    const size_t need_xyb = xyb_off(p, p.nscales) + 4;
+    if (need_xyb > c->cap_xyb) {
+        (void)hipFree(c->d_xyb_ref);
+        c->d_xyb_ref = nullptr;
+        c->cap_xyb = 0;
+        hipError_t e = hipMalloc(&c->d_xyb_ref, need_xyb * sizeof(float));
+        if (e != hipSuccess) {
+            // not fatal: the search still works, the reference is just converted on every pass
+            c->d_xyb_ref = nullptr;
+            (void)hipGetLastError();
+        } else {
+            c->cap_xyb = need_xyb;
+        }
+    }
+    if (c->d_xyb_ref) {
+        for (int sc = 0; sc < p.nscales; ++sc) {
+            const size_t n = (size_t)p.w[sc] * p.h[sc];
+            const void* in = sc == 0 ? (const void*)c->d_ref_u8 : (const void*)(c->d_lin_ref + p.lin_off[sc]);
+            hipLaunchKernelGGL(k_ref_xyb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in,
+                               sc == 0, p.w[sc], p.h[sc], c->d_xyb_ref + xyb_off(p, sc));
+        }
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `ref` after return
@@ -485,6 +523,22 @@ int ssimu2_set_reference(ssimu2_ctx* c, const uint8_t* ref, uint32_t w, uint32_t
     c->ref_w = w;
     c->ref_h = h;
     return SSIMU2_OK;
+}
+
+int ssimu2_set_reference(ssimu2_ctx* c, const uint8_t* ref, uint32_t w, uint32_t h) {
+    return set_reference_impl(c, ref, w, h, hipMemcpyHostToDevice);
+}
+
+int ssimu2_set_reference_device(ssimu2_ctx* c, const void* d_ref, uint32_t w, uint32_t h) {
+    return set_reference_impl(c, d_ref, w, h, hipMemcpyDeviceToDevice);
+}
+
+int ssimu2_enqueue_against_reference_device(ssimu2_ctx* c, const void* d_dist) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!c->have_ref) return c->fail(SSIMU2_ERR_NO_REFERENCE, "no reference set");
+    if (!d_dist) return c->fail(SSIMU2_ERR_INVALID_ARG, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_score(c, c->d_ref_u8, (const uint8_t*)d_dist, c->ref_w, c->ref_h, true);
 }
 
 int ssimu2_score_against_reference(ssimu2_ctx* c, const uint8_t* dist, double* out_score) {
@@ -542,7 +596,7 @@ int ssimu2_time_stage(ssimu2_ctx* c, const void* d_ref, const void* d_dist, uint
     MarchPlan mp;
     FinalizeArgs fa;
     int blocks = 0;
-    build_plans(c, p, (const uint8_t*)d_ref, (const uint8_t*)d_dist, &mp, &fa, &blocks);
+    build_plans(c, p, (const uint8_t*)d_ref, (const uint8_t*)d_dist, false, &mp, &fa, &blocks);
     if (stage < 0 || stage > 2) return c->fail(SSIMU2_ERR_INVALID_ARG, "bad stage");
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < iters; ++i) {

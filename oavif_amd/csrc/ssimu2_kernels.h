@@ -273,6 +273,7 @@ struct MarchPlan {
     int w[kNumScales], h[kNumScales], seg[kNumScales], nstrips[kNumScales], nblocks[kNumScales];
     const void* ref[kNumScales];   // scale 0: u8 interleaved; others: fp32 planes
     const void* dist[kNumScales];
+    const float* ref_xyb[kNumScales];  // cached positive-XYB planes of the reference, or null
     double* part[kNumScales];      // [18][nblocks] partial sums of the scale
 };
 
@@ -325,6 +326,39 @@ __device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const fl
 #endif
 #pragma unroll
     for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
+}
+
+// Cached reference: the loaded values already are positive XYB (k_ref_xyb); store them.
+__device__ __forceinline__ void march_store_xyb(float (*ring)[2][3][MRW], const MarchRaw& raw, int slot,
+                                                int k, int col) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? __uint_as_float(raw.v[c]) : 0.0f;
+}
+
+// Positive-XYB planes of one frame at one scale (run once per search for the reference, whose
+// pixels are the same on every pass: tq.zig:37 passes the same e.rgb, main.zig:86).
+__global__ __launch_bounds__(256) void k_ref_xyb(const void* __restrict__ in, bool u8, int w, int h,
+                                                 float* __restrict__ out) {
+    const size_t n = (size_t)w * h;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float r, g, b;
+    if (u8) {
+        const uint8_t* p = (const uint8_t*)in + i * 3;
+        r = c_k.lut[p[0]];
+        g = c_k.lut[p[1]];
+        b = c_k.lut[p[2]];
+    } else {
+        const float* p = (const float*)in + i;
+        r = p[0];
+        g = p[n];
+        b = p[2 * n];
+    }
+    float X, Y, B;
+    linear_to_xyb(r, g, b, X, Y, B);
+    out[i] = X;
+    out[n + i] = Y;
+    out[2 * n + i] = B;
 }
 
 // LDS reads of one blur-wave step: the 9-wide x / y windows of ring row t and the centre pixel
@@ -467,24 +501,33 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     const int ngroups = (steps + GROUP - 1) / GROUP;
     if (is_conv) {
         const int col = (wave << 6) + lane;  // staged column; this lane converts both frames
+        // reference frame: cached positive-XYB planes (fp32, no conversion) when available
+        const bool ref_cached = plan.ref_xyb[sc] != nullptr;
+        const void* ref_src = ref_cached ? (const void*)plan.ref_xyb[sc] : plan.ref[sc];
+        const bool ref_u8 = u8 && !ref_cached;
         MarchRaw q[2][PF], nxt[2];  // per frame: q[0] = next row to convert, q[PF-1] = newest
+#define MARCH_PUT_REF(RAW, SLOT)                                            \
+    {                                                                       \
+        if (ref_cached) march_store_xyb(s_ring, RAW, SLOT, 0, col);         \
+        else march_convert(s_ring, s_lut, ref_u8, RAW, SLOT, 0, col);       \
+    }
 #pragma unroll
         for (int j0 = 0; j0 < AHEAD; j0 += GROUP) {
             MarchRaw first_rows[2][GROUP];
 #pragma unroll
             for (int j = 0; j < GROUP; ++j) {
-                march_load(first_rows[0][j], u8, plan.ref[sc], w, h, x0, y0 - RAD + j0 + j, col);
+                march_load(first_rows[0][j], ref_u8, ref_src, w, h, x0, y0 - RAD + j0 + j, col);
                 march_load(first_rows[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + j0 + j, col);
             }
 #pragma unroll
             for (int j = 0; j < GROUP; ++j) {
-                march_convert(s_ring, s_lut, u8, first_rows[0][j], j0 + j, 0, col);
+                MARCH_PUT_REF(first_rows[0][j], j0 + j)
                 march_convert(s_ring, s_lut, u8, first_rows[1][j], j0 + j, 1, col);
             }
         }
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            march_load(q[0][j], u8, plan.ref[sc], w, h, x0, y0 - RAD + AHEAD + j, col);
+            march_load(q[0][j], ref_u8, ref_src, w, h, x0, y0 - RAD + AHEAD + j, col);
             march_load(q[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + AHEAD + j, col);
         }
         MARCH_BARRIER();
@@ -494,9 +537,9 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
             for (int j = 0; j < GROUP; ++j) {
                 const int r = g * GROUP + j + AHEAD;  // ring row to produce
                 if (r < steps) {
-                    march_load(nxt[0], u8, plan.ref[sc], w, h, x0, y0 - RAD + r + PF, col);
+                    march_load(nxt[0], ref_u8, ref_src, w, h, x0, y0 - RAD + r + PF, col);
                     march_load(nxt[1], u8, plan.dist[sc], w, h, x0, y0 - RAD + r + PF, col);
-                    march_convert(s_ring, s_lut, u8, q[0][0], r & (RING - 1), 0, col);
+                    MARCH_PUT_REF(q[0][0], r & (RING - 1))
                     march_convert(s_ring, s_lut, u8, q[1][0], r & (RING - 1), 1, col);
 #pragma unroll
                     for (int k = 0; k + 1 < PF; ++k) {
@@ -509,6 +552,7 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
             }
             MARCH_BARRIER();
         }
+#undef MARCH_PUT_REF
     } else {
         float win[5][9];
         MARCH_BARRIER();
@@ -583,19 +627,27 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __re
         result[item] = v;
     }
     __syncthreads();
+    // published Score(): weights are consumed with a running index over (channel, scale present,
+    // norm, {ssim, artifact, detail}); term j of that walk is evaluated by thread j and the
+    // terms are summed with a fixed shuffle tree (two waves), then by thread 0.
+    __shared__ double s_red[2];
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x;
+        const int nterms = 3 * fa.nscales * 2 * 3;
+        double term = 0.0;
+        if (j < nterms) {
+            const int k = j % 3, n = (j / 3) & 1, cs = j / 6;
+            const int sc = cs % fa.nscales, c = cs / fa.nscales;
+            const double* a = s_avg + sc * kStats;
+            const double val = k == 0 ? a[c * 2 + n] : a[6 + c * 4 + n + (k == 2 ? 2 : 0)];
+            term = c_k.weights[j] * fabs(val);
+        }
+        term = wave_sum(term);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = term;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // published Score(): running weight index over the scales actually present
-        double ssim = 0.0;
-        int i = 0;
-        for (int c = 0; c < 3; ++c)
-            for (int sc = 0; sc < fa.nscales; ++sc) {
-                const double* a = s_avg + sc * kStats;
-                for (int n = 0; n < 2; ++n) {
-                    ssim += c_k.weights[i++] * fabs(a[c * 2 + n]);
-                    ssim += c_k.weights[i++] * fabs(a[6 + c * 4 + n]);
-                    ssim += c_k.weights[i++] * fabs(a[6 + c * 4 + n + 2]);
-                }
-            }
+        double ssim = s_red[0] + s_red[1];
         ssim = ssim * 0.9562382616834844;
         ssim = 2.326765642916932 * ssim - 0.020884521182843837 * ssim * ssim +
                6.248496625763138e-05 * ssim * ssim * ssim;

@@ -112,6 +112,17 @@ class Ssimu2:
         if rc != 0:
             self._raise(rc)
 
+    def set_reference_device(self, d_ref: int, w: int, h: int) -> None:
+        rc = self._L.ssimu2_set_reference_device(self._ctx, ctypes.c_void_p(d_ref), w, h)
+        if rc != 0:
+            self._raise(rc)
+        self._ref_shape = (h, w, 3)
+
+    def enqueue_against_reference_device(self, d_dist: int) -> None:
+        rc = self._L.ssimu2_enqueue_against_reference_device(self._ctx, ctypes.c_void_p(d_dist))
+        if rc != 0:
+            self._raise(rc)
+
     def wait(self) -> float:
         out = ctypes.c_double()
         rc = self._L.ssimu2_wait(self._ctx, ctypes.byref(out))

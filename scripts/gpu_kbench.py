@@ -16,3 +16,13 @@ ks = [s.time_stage(tr.data_ptr(), td.data_ptr(), w, h, st, 30) * 1e3 for st in r
 ms, _ = s.time_device(tr.data_ptr(), td.data_ptr(), w, h, 50)
 tag = f"seg={os.environ.get('OAVIF_AMD_SEG_ROWS','auto')}"
 print(f"{tag}: score={score:.9f} stage_us[pyramid,march,finalize]={[round(k,1) for k in ks]} sum={sum(ks):.1f} whole_score_us={ms/50*1e3:.1f} MP/s={w*h/1e6/(ms/50/1e3):.0f}")
+s.set_reference_device(tr.data_ptr(), w, h)
+import time
+for _ in range(5):
+    s.enqueue_against_reference_device(td.data_ptr())
+sc2 = s.wait()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(100):
+    s.enqueue_against_reference_device(td.data_ptr())
+sc2 = s.wait(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
+print(f"cached-reference score: {sc2:.9f} (same={sc2 == score}) {dt*1e6:.1f} us/score  {w*h/1e6/dt:.0f} MP/s")

@@ -95,6 +95,28 @@ def test_set_reference_path_is_bit_identical(scorer):
     assert cached == [scorer.score_against_reference(d) for d in dists]
 
 
+def test_reference_cache_device_path(scorer):
+    import torch
+    ref = synth.make_ref(777, 333, 43)
+    dists = [synth.distort(ref, "blockq", s) for s in range(3)]
+    direct = [scorer.compute_ssimu2(ref, d) for d in dists]
+    t_ref = torch.from_numpy(ref).cuda().contiguous()
+    t_d = [torch.from_numpy(d).cuda().contiguous() for d in dists]
+    torch.cuda.synchronize()
+    scorer.set_reference_device(t_ref.data_ptr(), 777, 333)
+    got = []
+    for t in t_d:
+        scorer.enqueue_against_reference_device(t.data_ptr())
+        got.append(scorer.wait())
+    assert got == direct
+    # a plain pair score in between invalidates the cached reference
+    scorer.compute_ssimu2(ref, dists[0])
+    from oavif_amd import Ssimu2Error, _lib
+    with pytest.raises(Ssimu2Error) as ei:
+        scorer.enqueue_against_reference_device(t_d[0].data_ptr())
+    assert ei.value.code == _lib.ERR_NO_REFERENCE
+
+
 def test_device_resident_entry_points(scorer):
     import torch
     ref = synth.make_ref(400, 300, 51)
