@@ -280,3 +280,53 @@ def test_8k_properties(scorer):
     assert scorer.compute_ssimu2(ref, d1) == s1           # deterministic
     _, ns = scorer.last_averages()
     assert ns == 6
+
+
+@pytest.mark.parametrize("w,h", [(119, 40), (120, 40), (121, 40), (239, 33), (240, 33), (241, 33),
+                                 (128, 17), (136, 9), (360, 8), (361, 24), (1200, 16), (24, 400),
+                                 (9, 1000)])
+def test_strip_and_segment_boundaries(scorer, oracle, w, h):
+    """Widths around multiples of the 120-column strip, heights around the 8-row minimum
+    segment and the 16-row ring, very tall / very wide frames."""
+    rng = np.random.default_rng(w * 7919 + h)
+    ref = synth.make_ref(w, h, w + h)
+    dist = np.clip(ref.astype(np.int16) + rng.integers(-9, 10, ref.shape), 0, 255).astype(np.uint8)
+    _check_pair(scorer, oracle, ref, dist)
+
+
+def _content(kind, w, h, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "gradient":
+        img = np.stack([xx * 255 // max(w - 1, 1), yy * 255 // max(h - 1, 1),
+                        (xx + yy) * 255 // max(w + h - 2, 1)], -1)
+    elif kind == "primaries":      # saturated patches: exercises the opsin clamp / B-Y remap
+        cols = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255],
+                         [255, 0, 255], [0, 0, 0], [255, 255, 255]])
+        img = cols[((xx // 16) + (yy // 16)) % 8]
+    elif kind == "checker":        # 1-px checkerboard: maximal high-frequency energy
+        img = np.repeat((((xx + yy) & 1) * 255)[..., None], 3, -1)
+    elif kind == "text":           # thin dark strokes on light ground
+        img = np.full((h, w, 3), 235)
+        for _ in range(60):
+            x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+            img[y:y + 1 + int(rng.integers(0, 2)), x:x + int(rng.integers(3, 30))] = 20
+            img[y:y + int(rng.integers(3, 20)), x:x + 1] = 20
+    else:                          # white noise
+        img = rng.integers(0, 256, (h, w, 3))
+    return np.ascontiguousarray(img.astype(np.uint8))
+
+
+@pytest.mark.parametrize("kind", ["gradient", "primaries", "checker", "text", "noise"])
+def test_content_types(scorer, oracle, kind):
+    ref = _content(kind, 250, 190, 5)
+    for dk, ds in [("blur", 0), ("band", 2), ("noise", 2)]:
+        _check_pair(scorer, oracle, ref, synth.distort(ref, dk, ds, seed=3), tol=5e-4)
+
+
+def test_one_pixel_difference_is_detected(scorer, oracle):
+    ref = synth.make_ref(200, 150, 77)
+    d = ref.copy()
+    d[75, 100] = 255 - d[75, 100]
+    got, exp = _check_pair(scorer, oracle, ref, d)
+    assert got < 100.0
