@@ -1,0 +1,341 @@
+"""`oavif` command-line surface over the MI355X scorer.
+
+    python -m oavif_amd.cli [options] <in> <out.avif>
+
+Mirrors /root/reference/src/main.zig (driver flow, stderr line formats) and
+/root/reference/src/parse_args.zig (flags, ranges, defaults, error messages) so that tools
+written against the reference -- scripts/measure.py parses "N passes" from stderr
+(measure.py:27) -- keep working.  The code's behaviour wins where the reference's README
+disagrees with it: --quality-alpha default 0 / max 99, --score-tgt min 30.
+
+What runs where: argument parsing and the search control are this repo's (the search is
+oavif_amd.tq over the C ABI); the SSIMULACRA2 score of every pass runs on the GPU; the AVIF
+encode / decode stay on the CPU in libavif (aom / dav1d) -- here through Pillow's bundled
+libavif, because the build image has no libavif headers.  Pillow's binding is 8-bit only, so
+`--tenbit 1` (the default) is accepted and reported, but the bitstream it writes is 8-bit;
+the scorer input is 8-bit RGB either way (io.zig:470-471).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+VERSION = "oavif_amd-0.1"
+
+
+class CliError(Exception):
+    """Carries the reference's Zig error name (e.g. MissingOptionValue)."""
+
+    def __init__(self, name: str):
+        super().__init__(name)
+        self.name = name
+
+
+def eprint(s: str = "", end: str = "\n") -> None:
+    sys.stderr.write(s + end)
+
+
+@dataclass
+class AvifEncOptions:  # parse_args.zig:48-63
+    quality_alpha: int = 0
+    speed: int = 9
+    max_threads: int = 1
+    tile_rows_log2: int = 0
+    tile_cols_log2: int = 0
+    auto_tiling: bool = True
+    score_tgt: float = 80.0
+    tenbit: bool = True
+    tune: str = "iq"
+    tolerance: float = 2.0
+    max_pass: int = 6
+    quality: Optional[int] = None
+    color_primaries: int = 2
+    transfer_characteristics: int = 2
+    matrix_coefficients: int = 2
+
+
+TUNE_MODES = ("ssim", "iq", "ssimulacra2")  # parse_args.zig:26-45
+
+
+def _fmt_num(v) -> str:
+    """Zig's {d} on an f64 bound prints 30 for 30.0."""
+    return str(int(v)) if float(v).is_integer() else str(v)
+
+
+def _value(args: List[str], i: int, name: str) -> str:
+    # parse_args.zig:126,140,154,168: a value that starts with '-' counts as missing
+    if i >= len(args) or args[i].startswith("-"):
+        eprint(f"Error: Missing {name} value")
+        raise CliError("MissingOptionValue")
+    return args[i]
+
+
+def _int_arg(args, i, lo, hi, name) -> int:
+    s = _value(args, i, name)
+    try:
+        v = int(s, 10)
+    except ValueError:
+        raise CliError("InvalidCharacter")
+    if v < lo or v > hi:
+        eprint(f"Error: {name} must be between {lo} and {hi}")
+        raise CliError("InvalidOptionValue")
+    return v
+
+
+def _float_arg(args, i, lo, hi, name) -> float:
+    s = _value(args, i, name)
+    try:
+        v = float(s)
+    except ValueError:
+        raise CliError("InvalidCharacter")
+    if v < lo or v > hi:
+        eprint(f"Error: {name} must be between {_fmt_num(lo)} and {_fmt_num(hi)}")
+        raise CliError("InvalidOptionValue")
+    return v
+
+
+def _bool_arg(args, i, name) -> bool:
+    s = _value(args, i, name)
+    try:
+        v = int(s, 10)
+    except ValueError:
+        raise CliError("InvalidCharacter")
+    if v not in (0, 1):
+        eprint(f"Error: {name} must be 0 or 1")
+        raise CliError("InvalidOptionValue")
+    return v == 1
+
+
+def parse_args(argv: List[str]) -> Tuple[AvifEncOptions, Optional[str], Optional[str]]:
+    """parse_args.zig:76-122.  argv excludes the program name."""
+    o = AvifEncOptions()
+    inp = out = None
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        i += 1
+        if a in ("-s", "--speed"):
+            o.speed = _int_arg(argv, i, 0, 10, "--speed"); i += 1
+        elif a in ("-t", "--score-tgt"):
+            o.score_tgt = _float_arg(argv, i, 30.0, 100.0, "--score-tgt"); i += 1
+        elif a == "--quality-alpha":
+            o.quality_alpha = _int_arg(argv, i, 0, 99, a); i += 1
+        elif a == "--max-threads":
+            o.max_threads = _int_arg(argv, i, 1, 255, a); i += 1
+        elif a == "--tile-rows-log2":
+            o.tile_rows_log2 = _int_arg(argv, i, 0, 6, a); i += 1
+        elif a == "--tile-cols-log2":
+            o.tile_cols_log2 = _int_arg(argv, i, 0, 6, a); i += 1
+        elif a == "--auto-tiling":
+            o.auto_tiling = _bool_arg(argv, i, a); i += 1
+        elif a == "--tune":
+            s = _value(argv, i, a)
+            if s not in TUNE_MODES:
+                eprint(f"Error: {a} must be one of: ssim, iq, ssimulacra2")
+                raise CliError("InvalidOptionValue")
+            o.tune = s; i += 1
+        elif a == "--tenbit":
+            o.tenbit = _bool_arg(argv, i, a); i += 1
+        elif a == "--tolerance":
+            o.tolerance = _float_arg(argv, i, 1.0, 100.0, a); i += 1
+        elif a == "--max-pass":
+            o.max_pass = _int_arg(argv, i, 1, 12, a); i += 1
+        elif a in ("-q", "--quality"):
+            o.quality = _int_arg(argv, i, 0, 100, "--quality"); i += 1
+        elif a == "--color-primaries":
+            o.color_primaries = _int_arg(argv, i, 1, 22, a); i += 1
+        elif a == "--transfer-characteristics":
+            o.transfer_characteristics = _int_arg(argv, i, 1, 18, a); i += 1
+        elif a == "--matrix-coefficients":
+            o.matrix_coefficients = _int_arg(argv, i, 0, 14, a); i += 1
+        elif inp is None:
+            inp = a
+        elif out is None:
+            out = a
+        else:
+            eprint(f"Error: Unexpected argument: {a}")
+            raise CliError("UnexpectedArgument")
+    return o, inp, out
+
+
+def print_usage() -> None:  # parse_args.zig:180-238
+    d = AvifEncOptions()
+    eprint()
+    eprint(f"""usage:  oavif [options] <in> <out.avif>
+
+options:
+ -h, --help
+    show this help
+ -v, --version
+    show version information
+ -s, --speed u8
+    encoder speed (0..10) [{d.speed}]
+ -t, --score-tgt f64
+    target SSIMULACRA2 score (0..100) [{d.score_tgt:.0f}]
+ --quality-alpha u8
+    quality factor for alpha (0..100=lossless) [{d.quality_alpha}]
+ --max-threads u8
+    maximum number of threads to use (1..255) [{d.max_threads}]
+ --tile-rows-log2 u8
+    tile rows log2 (0..6) [{d.tile_rows_log2}]
+ --tile-cols-log2 u8
+    tile columns log2 (0..6) [{d.tile_cols_log2}]
+ --auto-tiling 0/1
+    enable automatic tiling [{int(d.auto_tiling)}]
+ --tune str
+    libaom tuning mode (ssim, iq, ssimulacra2) [{d.tune}]
+ --tenbit 0/1
+    force 10-bit AVIF output [{int(d.tenbit)}]
+ --tolerance f64
+    target quality error tolerance (1..100) [{d.tolerance:.0f}]
+ --max-pass u8
+    maximum search passes (1..12) [{d.max_pass}]
+ -q, --quality u8
+    quantizer (0..100), bypasses search
+ --color-primaries u8
+    color primaries (1..22) [{d.color_primaries}]
+ --transfer-characteristics u8
+    transfer characteristics (1..18) [{d.transfer_characteristics}]
+ --matrix-coefficients u8
+    matrix coefficients (0..14) [{d.matrix_coefficients}]""", end="")
+    eprint("\n\n\x1b[37mInput image formats: PNG, PAM, JPEG, WebP, or AVIF\x1b[0m")
+
+
+def print_version() -> None:
+    from PIL import features
+    import oavif_amd
+    eprint(f"oavif {VERSION}")
+    eprint(f"scorer {oavif_amd.version()}")
+    eprint(f"libavif {features.version('avif')} (via Pillow)")
+
+
+# ---- image I/O (CPU; counterpart of io.zig) -------------------------------------------------------
+
+def load_image(path: str):
+    """io.loadImage + Image.toRGB8 (io.zig:57-150): -> (rgb8 (h,w,3) u8, src PIL image, channels,
+    hbd).  16-bit sources are truncated with >> 8, alpha is dropped, gray is replicated."""
+    import numpy as np
+    from PIL import Image
+    ext = os.path.splitext(path)[1].lower()
+    if ext not in (".jpg", ".jpeg", ".png", ".pam", ".webp", ".avif"):
+        raise CliError("UnsupportedImageFormat")
+    if ext == ".pam":
+        from .pam import load_pam
+        data, w, h, ch = load_pam(open(path, "rb").read())
+        arr = np.frombuffer(data, np.uint8).reshape(h, w, ch)
+        hbd = False
+    else:
+        im = Image.open(path)
+        hbd = im.mode in ("I;16", "I;16B", "I;16L", "I")
+        if hbd:
+            arr = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)[..., None]
+        else:
+            if im.mode not in ("L", "LA", "RGB", "RGBA"):
+                im = im.convert("RGBA" if "A" in im.getbands() or "transparency" in im.info else "RGB")
+            arr = np.asarray(im)
+            if arr.ndim == 2:
+                arr = arr[..., None]
+    ch = arr.shape[2]
+    if ch == 1 or ch == 2:
+        rgb = np.repeat(arr[..., :1], 3, axis=2)
+    else:
+        rgb = arr[..., :3]
+    return np.ascontiguousarray(rgb), arr, ch, hbd
+
+
+def _encode(src, o: AvifEncOptions, q: int) -> bytes:
+    """io.encodeAvifToBuffer (io.zig:544-636) through Pillow: YUV444, the options of copyToEncoder."""
+    import io as _io
+    from PIL import Image
+    mode = {1: "L", 2: "LA", 3: "RGB", 4: "RGBA"}[src.shape[2]]
+    im = Image.fromarray(src[..., 0] if src.shape[2] == 1 else src, mode)
+    buf = _io.BytesIO()
+    im.save(buf, format="AVIF", quality=int(q), subsampling="4:4:4", speed=o.speed,
+            max_threads=o.max_threads, tile_rows=o.tile_rows_log2, tile_cols=o.tile_cols_log2,
+            autotiling=o.auto_tiling, advanced={"tune": o.tune} if o.tune == "ssim" else None)
+    return buf.getvalue()
+
+
+def _decode_rgb(data: bytes):
+    from . import synth
+    return synth.avif_decode(data)  # io.decodeAvifToRgb: 8-bit, alpha dropped (io.zig:638-666)
+
+
+# ---- driver (main.zig:37-117) -----------------------------------------------------------------------
+
+def main(argv: Optional[List[str]] = None, scorer=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    eprint(f"\x1b[31moavif\x1b[0m | {VERSION}")
+    show_help = show_version = False
+    for a in argv:  # only honoured while they are the leading arguments (main.zig:50-59)
+        if a in ("--help", "-h"):
+            show_help = True
+        elif a in ("--version", "-v"):
+            show_version = True
+        else:
+            break
+    if show_help:
+        print_usage()
+        return 0
+    if show_version:
+        print_version()
+        return 0
+    own_scorer = False
+    try:
+        o, inp, out = parse_args(argv)
+        if inp is None or out is None:
+            raise CliError("MissingInputOrOutput")
+        rgb, src, channels, hbd = load_image(inp)
+        h, w, _ = rgb.shape
+        eprint(f"Read {w}x{h}, {'RGBA' if channels > 3 else 'RGB'}, {16 if hbd else 8}-bit, "
+               f"{os.path.getsize(inp)} bytes")
+        out_depth = 10 if o.tenbit else (10 if hbd else 8)
+        if o.quality is not None:  # bypass the search (main.zig:93-100)
+            eprint(f"Encoding [q{o.quality}, speed {o.speed}, {out_depth}-bit]")
+            data = _encode(src, o, o.quality)
+            open(out, "wb").write(data)
+            eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
+            return 0
+
+        eprint(f"Searching [tgt {_fmt_num(o.score_tgt)}±{o.tolerance:.1f}, speed {o.speed}, {out_depth}-bit]")
+        from . import tq
+        if scorer is None:
+            from . import Ssimu2
+            scorer = Ssimu2(int(os.environ.get("LOCAL_RANK", "0")))
+            own_scorer = True
+        cache = {}
+
+        def codec(q: int):
+            data = _encode(src, o, q)
+            cache.clear()
+            cache[q] = data  # EncBuffer keeps only the last probe (tq.zig:31-35)
+            return _decode_rgb(data), len(data)
+
+        r = tq.search_hip(scorer, rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                          max_pass=o.max_pass)
+        eprint(f"Found q{r.q} (score {r.score:.2f}, {r.num_pass} passes)")
+        data = cache.get(r.q) if r.buf_q == r.q else None
+        if data is None:  # main.zig:109-113
+            data = _encode(src, o, r.q)
+        open(out, "wb").write(data)
+        eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
+        return 0
+    except CliError as e:
+        eprint(f"error: {e.name}")
+        return 1
+    except FileNotFoundError:
+        eprint("error: FileNotFound")
+        return 1
+    except Exception as e:  # codec / scorer failures end the run like any Zig error (main.zig:103)
+        name = getattr(e, "name", type(e).__name__)
+        eprint(f"error: {name}: {e}")
+        return 1
+    finally:
+        if own_scorer and scorer is not None:
+            scorer.close()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

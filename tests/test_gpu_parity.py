@@ -330,3 +330,33 @@ def test_one_pixel_difference_is_detected(scorer, oracle):
     d[75, 100] = 255 - d[75, 100]
     got, exp = _check_pair(scorer, oracle, ref, d)
     assert got < 100.0
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+def test_cli_search_end_to_end(scorer, tmp_path, capsys):
+    """`oavif in.png out.avif` surface: stderr lines as main.zig prints them, measure.py's
+    "N passes" contract, file written at the chosen quantizer."""
+    import re
+    from PIL import Image
+    from oavif_amd import cli
+    src = tmp_path / "in.png"
+    ref = synth.make_ref(320, 240, 303)
+    Image.fromarray(ref).save(src)
+    out = tmp_path / "out.avif"
+    assert cli.main(["--score-tgt", "75", "--tolerance", "1.5", str(src), str(out)], scorer=scorer) == 0
+    err = capsys.readouterr().err.splitlines()
+    assert err[1].startswith("Read 320x240, RGB, 8-bit, ")
+    assert err[2] == "Searching [tgt 75±1.5, speed 9, 10-bit]"
+    m = re.fullmatch(r"Found q(\d+) \(score (-?\d+\.\d{2}), (\d+) passes\)", err[3])
+    assert m, err[3]
+    assert re.search(r"(\d+)\s+passes?", err[3]).group(1) == m.group(3)      # measure.py:27
+    assert re.fullmatch(r"Compressed to \d+ bytes \(\d+\.\d{3} bpp\)", err[4])
+    dec = synth.avif_decode(out.read_bytes())
+    assert abs(scorer.compute_ssimu2(ref, dec) - float(m.group(2))) < 0.006
+    # PAM input and a 4-channel source go through the same path (alpha dropped for the scorer)
+    from oavif_amd import pam
+    rgba = np.dstack([ref, np.full(ref.shape[:2], 200, np.uint8)])
+    p = tmp_path / "in.pam"
+    p.write_bytes(pam.write_pam(rgba))
+    assert cli.main([str(p), str(tmp_path / "o2.avif")], scorer=scorer) == 0
+    assert "Read 320x240, RGBA, 8-bit" in capsys.readouterr().err
