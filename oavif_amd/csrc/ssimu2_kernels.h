@@ -83,6 +83,38 @@ __device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& 
     Y = y + 0.01f;
 }
 
+// Same values as linear_to_xyb for non-negative linear inputs, which is all the marching kernel
+// ever sees (LUT entries and their 2x2 averages are >= 0, so every opsin sum is >= the bias):
+// the published clamp to zero and cbrt_repro's x > 0 guard can never act and are left out.
+__device__ __forceinline__ float cbrt_repro_pos(float x) {
+    uint32_t i = __float_as_uint(x);
+    i = 0x54A2FA8Cu - i / 3u;
+    float y = __uint_as_float(i);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float t = x * y;
+        t = t * y;
+        t = t * y;
+        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
+    }
+    const float y2 = y * y;
+    float c = x * y2;
+    const float r = fmaf(c * c, c, -x);
+    return fmaf(r, y2 * (-1.0f / 3.0f), c);
+}
+
+__device__ __forceinline__ void linear_to_xyb_pos(float r, float g, float b, float& X, float& Y,
+                                                  float& B) {
+    const float cb = c_k.cbrt_bias;
+    const float l = cbrt_repro_pos(fmaf(kM00, r, fmaf(kM01, g, fmaf(kM02, b, kOpsinBias)))) - cb;
+    const float m = cbrt_repro_pos(fmaf(kM10, r, fmaf(kM11, g, fmaf(kM12, b, kOpsinBias)))) - cb;
+    const float s = cbrt_repro_pos(fmaf(kM20, r, fmaf(kM21, g, fmaf(kM22, b, kOpsinBias)))) - cb;
+    const float x = 0.5f * (l - m), y = 0.5f * (l + m);
+    B = (s - y) + 0.55f;
+    X = fmaf(x, 14.0f, 0.42f);
+    Y = y + 0.01f;
+}
+
 // symmetric 9-tap in the contract's operation order: one mul, four FMAs.
 __device__ __forceinline__ float fir9(float c, float s1, float s2, float s3, float s4, float w0,
                                       float w1, float w2, float w3, float w4) {
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
 //   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128), both frames.  Each
 //     step they convert one input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive XYB)
 //     into an LDS ring of raw rows, two barrier groups ahead of the blur waves; their global
-//     loads run PF more rows ahead, so HBM latency is off the critical path.
+//     loads run one more group ahead, so HBM latency is off the critical path.
 //   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
 //     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
 //     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
@@ -265,7 +297,6 @@ constexpr int AHEAD = 2 * 3;   // rows the converters run ahead of the blur wave
 constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
 constexpr int MARCH_THREADS = 512;
 constexpr int CONV_WAVES = 2;  // each converter lane handles one staged column of BOTH frames
-constexpr int PF = 4;          // rows the converters' global loads run ahead of the conversion
 
 struct MarchPlan {
     int nscales;
@@ -283,26 +314,45 @@ struct MarchRaw {
     bool ok;
 };
 
-// Issue the global loads of input row r, staged column `col` (global x = x0 - 4 + col).
-__device__ __forceinline__ void march_load(MarchRaw& raw, bool u8, const void* __restrict__ img,
-                                           int w, int h, int x0, int r, int col) {
-    const int gx = x0 - RAD + col;
-    raw.ok = r >= 0 && r < h && gx >= 0 && gx < w;
-    raw.v[0] = raw.v[1] = raw.v[2] = 0;
-    if (raw.ok) {
-        if (u8) {
-            const uint8_t* p = (const uint8_t*)img + ((size_t)r * w + gx) * 3;
-            raw.v[0] = p[0];
-            raw.v[1] = p[1];
-            raw.v[2] = p[2];
+// Per-lane read cursor over one frame: address of this lane's (column-clamped) pixel in the
+// next row to load; advanced by one row pitch per load, so no per-row 64-bit address math.
+struct MarchSrc {
+    const uint8_t* p;  // u8: interleaved RGB; otherwise fp32 planes
+    size_t plane;      // plane stride in elements (fp32 sources)
+    int pitch;         // bytes per row
+    bool u8;
+};
+
+__device__ __forceinline__ MarchSrc march_src(const void* base, bool u8, int w, int h, int gx,
+                                              int first_row) {
+    MarchSrc s;
+    const int gxc = min(max(gx, 0), w - 1);  // clamped: the value is discarded when gx is outside
+    s.u8 = u8;
+    s.plane = (size_t)w * h;
+    s.pitch = u8 ? w * 3 : w * 4;
+    s.p = (const uint8_t*)base + (ptrdiff_t)first_row * s.pitch + (size_t)gxc * (u8 ? 3 : 4);
+    return s;
+}
+
+// Issue the global loads of the cursor's row and advance it.  `row_ok` (the row is inside the
+// image) is uniform over the workgroup; rows outside are never dereferenced.
+__device__ __forceinline__ void march_load(MarchRaw& raw, MarchSrc& s, bool row_ok, bool col_ok) {
+    raw.ok = row_ok && col_ok;
+    if (row_ok) {
+        if (s.u8) {
+            raw.v[0] = s.p[0];
+            raw.v[1] = s.p[1];
+            raw.v[2] = s.p[2];
         } else {
-            const size_t n = (size_t)w * h;
-            const uint32_t* p = (const uint32_t*)img + (size_t)r * w + gx;
-            raw.v[0] = p[0];
-            raw.v[1] = p[n];
-            raw.v[2] = p[2 * n];
+            const uint32_t* q = (const uint32_t*)s.p;
+            raw.v[0] = q[0];
+            raw.v[1] = q[s.plane];
+            raw.v[2] = q[2 * s.plane];
         }
+    } else {
+        raw.v[0] = raw.v[1] = raw.v[2] = 0;
     }
+    s.p += s.pitch;
 }
 
 // Convert the loaded pixel to positive XYB and store it into ring slot `slot` of frame k
@@ -322,7 +372,7 @@ __device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const fl
 #ifdef ABL_NOCONV
     v[0] = rr; v[1] = gg; v[2] = bb;
 #else
-    linear_to_xyb(rr, gg, bb, v[0], v[1], v[2]);
+    linear_to_xyb_pos(rr, gg, bb, v[0], v[1], v[2]);
 #endif
 #pragma unroll
     for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
@@ -388,23 +438,21 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
                                               float w0, float w1, float w2, float w3, float w4) {
     MarchTaps cur;
     march_hv_fetch(cur, ring, t, ch, o);
-#define H9(e) fir9(e(4), e(3) + e(5), e(2) + e(6), e(1) + e(7), e(0) + e(8), w0, w1, w2, w3, w4)
-#define EX(q) cur.x[q]
-#define EY(q) cur.y[q]
-#define EXX(q) (cur.x[q] * cur.x[q])
-#define EYY(q) (cur.y[q] * cur.y[q])
-#define EXY(q) (cur.x[q] * cur.y[q])
-    win[0][P] = H9(EX);
-    win[1][P] = H9(EY);
-    win[2][P] = H9(EXX);
-    win[3][P] = H9(EYY);
-    win[4][P] = H9(EXY);
-#undef EX
-#undef EY
-#undef EXX
-#undef EYY
-#undef EXY
+    // plain planes: pair sums of the taps; product planes: the products are formed inside the
+    // pair sums as fma(a-, b-, a+ * b+) -- one rounding and one operation fewer than two
+    // products and an add (arithmetic contract, mirrored by the CPU checker)
+#define H9(v) \
+    fir9(v[4], v[3] + v[5], v[2] + v[6], v[1] + v[7], v[0] + v[8], w0, w1, w2, w3, w4)
+#define H9P(a, b)                                                                              \
+    fir9(a[4] * b[4], fmaf(a[3], b[3], a[5] * b[5]), fmaf(a[2], b[2], a[6] * b[6]),            \
+         fmaf(a[1], b[1], a[7] * b[7]), fmaf(a[0], b[0], a[8] * b[8]), w0, w1, w2, w3, w4)
+    win[0][P] = H9(cur.x);
+    win[1][P] = H9(cur.y);
+    win[2][P] = H9P(cur.x, cur.x);
+    win[3][P] = H9P(cur.y, cur.y);
+    win[4][P] = H9P(cur.x, cur.y);
 #undef H9
+#undef H9P
     const float r1 = cur.r1, r2 = cur.r2;
 #ifdef ABL_NOVMAPS
     if (t >= 8) { acc[0] += win[0][(P + 5) % 9] + win[1][P] + win[2][P] + win[3][P] + win[4][P]; }
@@ -501,58 +549,54 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     const int ngroups = (steps + GROUP - 1) / GROUP;
     if (is_conv) {
         const int col = (wave << 6) + lane;  // staged column; this lane converts both frames
+        const int gx = x0 - RAD + col;
+        const bool col_ok = gx >= 0 && gx < w;
         // reference frame: cached positive-XYB planes (fp32, no conversion) when available
         const bool ref_cached = plan.ref_xyb[sc] != nullptr;
-        const void* ref_src = ref_cached ? (const void*)plan.ref_xyb[sc] : plan.ref[sc];
-        const bool ref_u8 = u8 && !ref_cached;
-        MarchRaw q[2][PF], nxt[2];  // per frame: q[0] = next row to convert, q[PF-1] = newest
-#define MARCH_PUT_REF(RAW, SLOT)                                            \
-    {                                                                       \
-        if (ref_cached) march_store_xyb(s_ring, RAW, SLOT, 0, col);         \
-        else march_convert(s_ring, s_lut, ref_u8, RAW, SLOT, 0, col);       \
+        MarchSrc src0 = march_src(ref_cached ? (const void*)plan.ref_xyb[sc] : plan.ref[sc],
+                                  u8 && !ref_cached, w, h, gx, y0 - RAD);
+        MarchSrc src1 = march_src(plan.dist[sc], u8, w, h, gx, y0 - RAD);
+        int load_row = y0 - RAD;  // image row the cursors point at
+#define MARCH_LOAD2(Q0, Q1)                                          \
+    {                                                                \
+        const bool row_ok = load_row >= 0 && load_row < h;           \
+        march_load(Q0, src0, row_ok, col_ok);                        \
+        march_load(Q1, src1, row_ok, col_ok);                        \
+        ++load_row;                                                  \
     }
+#define MARCH_PUT2(Q0, Q1, SLOT)                                            \
+    {                                                                       \
+        if (ref_cached) march_store_xyb(s_ring, Q0, SLOT, 0, col);          \
+        else march_convert(s_ring, s_lut, src0.u8, Q0, SLOT, 0, col);       \
+        march_convert(s_ring, s_lut, u8, Q1, SLOT, 1, col);                 \
+    }
+        // q[f][j]: loaded, not yet converted row of frame f; slot j is refilled every GROUP rows,
+        // so the GROUP-deep prefetch queue rotates with the unrolled group (no register moves)
+        MarchRaw q[2][GROUP];
 #pragma unroll
-        for (int j0 = 0; j0 < AHEAD; j0 += GROUP) {
-            MarchRaw first_rows[2][GROUP];
+        for (int j0 = 0; j0 < AHEAD; j0 += GROUP) {  // prologue: ring rows 0 .. AHEAD-1
 #pragma unroll
-            for (int j = 0; j < GROUP; ++j) {
-                march_load(first_rows[0][j], ref_u8, ref_src, w, h, x0, y0 - RAD + j0 + j, col);
-                march_load(first_rows[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + j0 + j, col);
-            }
+            for (int j = 0; j < GROUP; ++j) MARCH_LOAD2(q[0][j], q[1][j])
 #pragma unroll
-            for (int j = 0; j < GROUP; ++j) {
-                MARCH_PUT_REF(first_rows[0][j], j0 + j)
-                march_convert(s_ring, s_lut, u8, first_rows[1][j], j0 + j, 1, col);
-            }
+            for (int j = 0; j < GROUP; ++j) MARCH_PUT2(q[0][j], q[1][j], j0 + j)
         }
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            march_load(q[0][j], ref_u8, ref_src, w, h, x0, y0 - RAD + AHEAD + j, col);
-            march_load(q[1][j], u8, plan.dist[sc], w, h, x0, y0 - RAD + AHEAD + j, col);
-        }
+        for (int j = 0; j < GROUP; ++j) MARCH_LOAD2(q[0][j], q[1][j])  // rows AHEAD .. AHEAD+2
         MARCH_BARRIER();
 #pragma unroll 1
         for (int g = 0; g < ngroups; ++g) {
 #pragma unroll
             for (int j = 0; j < GROUP; ++j) {
-                const int r = g * GROUP + j + AHEAD;  // ring row to produce
+                const int r = g * GROUP + j + AHEAD;  // ring row to produce (uniform)
                 if (r < steps) {
-                    march_load(nxt[0], ref_u8, ref_src, w, h, x0, y0 - RAD + r + PF, col);
-                    march_load(nxt[1], u8, plan.dist[sc], w, h, x0, y0 - RAD + r + PF, col);
-                    MARCH_PUT_REF(q[0][0], r & (RING - 1))
-                    march_convert(s_ring, s_lut, u8, q[1][0], r & (RING - 1), 1, col);
-#pragma unroll
-                    for (int k = 0; k + 1 < PF; ++k) {
-                        q[0][k] = q[0][k + 1];
-                        q[1][k] = q[1][k + 1];
-                    }
-                    q[0][PF - 1] = nxt[0];
-                    q[1][PF - 1] = nxt[1];
+                    MARCH_PUT2(q[0][j], q[1][j], r & (RING - 1))
+                    MARCH_LOAD2(q[0][j], q[1][j])  // row r + GROUP, consumed next iteration
                 }
             }
             MARCH_BARRIER();
         }
-#undef MARCH_PUT_REF
+#undef MARCH_LOAD2
+#undef MARCH_PUT2
     } else {
         float win[5][9];
         MARCH_BARRIER();

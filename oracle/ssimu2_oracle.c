@@ -211,6 +211,34 @@ static void fir_line(const or_gauss* rg, const float* in, ptrdiff_t n_in, ptrdif
 #undef AT
 }
 
+/* Horizontal 9-tap of the product plane a*b without materialising it: the centre tap is
+   a*b, every symmetric pair sum is fma(a[-d], b[-d], a[+d]*b[+d]) (one rounding fewer than
+   two products and an add, and one operation fewer: the HIP kernels do exactly this). */
+static void fir_line_prod(const or_gauss* rg, const float* a, const float* b, ptrdiff_t n_in,
+                          float* out) {
+    const float w0 = rg->fir[0], w1 = rg->fir[1], w2 = rg->fir[2], w3 = rg->fir[3],
+                w4 = rg->fir[4];
+#define A(i) (((i) >= 0 && (i) < n_in) ? a[i] : 0.0f)
+#define B(i) (((i) >= 0 && (i) < n_in) ? b[i] : 0.0f)
+#define PAIR(d) fmaf(A(n - (d)), B(n - (d)), A(n + (d)) * B(n + (d)))
+    for (ptrdiff_t n = 0; n < n_in; ++n) {
+        float acc = w0 * (A(n) * B(n));
+        acc = fmaf(w1, PAIR(1), acc);
+        acc = fmaf(w2, PAIR(2), acc);
+        acc = fmaf(w3, PAIR(3), acc);
+        acc = fmaf(w4, PAIR(4), acc);
+        out[n] = acc;
+    }
+#undef PAIR
+#undef A
+#undef B
+}
+
+/* 2-D blur of the product plane a*b (FIR mode: products formed inside the horizontal pass,
+   see fir_line_prod; IIR mode: the published form, product plane materialised first). */
+static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const float* b, size_t w,
+                            size_t h, float* prod_tmp, float* tmp, float* out);
+
 /* 2-D blur of one w*h plane: horizontal into tmp, vertical into out. */
 static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, size_t h,
                        float* tmp, float* out) {
@@ -224,6 +252,22 @@ static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, 
         if (mode == OR_BLUR_IIR) iir_line(rg, tmp + x, h, w, out + x, w);
         else fir_line(rg, tmp + x, h, w, out + x, w);
     }
+}
+
+static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const float* b, size_t w,
+                            size_t h, float* prod_tmp, float* tmp, float* out) {
+    if (mode == OR_BLUR_IIR) {
+        const size_t n = w * h;
+#pragma omp parallel for schedule(static)
+        for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) prod_tmp[i] = a[i] * b[i];
+        blur_plane(rg, mode, prod_tmp, w, h, tmp, out);
+        return;
+    }
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t y = 0; y < (ptrdiff_t)h; ++y)
+        fir_line_prod(rg, a + y * w, b + y * w, w, tmp + y * w);
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t x = 0; x < (ptrdiff_t)w; ++x) fir_line(rg, tmp + x, h, w, out + x, w);
 }
 
 /* exported for tests: blur one plane */
@@ -468,15 +512,9 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
         for (int c = 0; c < 3; ++c) {
             const float *a = img1 + c * n, *b = img2 + c * n;
             float* m = mul + c * n;
-#pragma omp parallel for schedule(static)
-            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = a[i] * a[i];
-            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s11 + c * n);
-#pragma omp parallel for schedule(static)
-            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = b[i] * b[i];
-            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s22 + c * n);
-#pragma omp parallel for schedule(static)
-            for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) m[i] = a[i] * b[i];
-            blur_plane(&rg, blur_mode, m, cw, ch, tmp, s12 + c * n);
+            blur_plane_prod(&rg, blur_mode, a, a, cw, ch, m, tmp, s11 + c * n);
+            blur_plane_prod(&rg, blur_mode, b, b, cw, ch, m, tmp, s22 + c * n);
+            blur_plane_prod(&rg, blur_mode, a, b, cw, ch, m, tmp, s12 + c * n);
             blur_plane(&rg, blur_mode, a, cw, ch, tmp, mu1 + c * n);
             blur_plane(&rg, blur_mode, b, cw, ch, tmp, mu2 + c * n);
         }
