@@ -142,6 +142,7 @@ struct ssimu2_ctx {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int seg_rows_override = 0;
+    int seg_rows_tail_override = 0;  // scales >= 1 (experiments)
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
@@ -190,23 +191,31 @@ Pyramid make_pyramid(uint32_t w, uint32_t h) {
     return p;
 }
 
-// Rows per workgroup of the marching kernel.  Three 8-wave workgroups fit a CU, so 768
-// workgroups are one fully balanced resident round of the 256 CUs; aim at that for the
-// full-resolution scale, but keep a segment between 8 rows (vertical halo cost 8/seg) and
-// 160 rows (fp32 partial sums).
-int march_seg_rows(const ssimu2_ctx* c, int w, int h) {
-    if (c->seg_rows_override > 0) return c->seg_rows_override;
-    const int nstrips = (w + MW - 1) / MW;
-    int nsegs = (768 + nstrips / 2) / nstrips;
-    if (nsegs < 1) nsegs = 1;
-    int seg = (h + nsegs - 1) / nsegs;
+// Rows per workgroup (segment length) of the marching kernel.  A segment of R rows costs R + 8
+// rows of conversion and horizontal blur, so longer is cheaper; shorter gives more workgroups
+// to balance.  Measured on MI355X at 4K (scripts/gpu_sweep2.sh): the full-resolution scale is
+// best at ~512 workgroups (two thirds of the 768 resident slots, 6 % halo), the smaller scales
+// at a fixed ~48 rows -- their few, long workgroups overlap the tail of scale 0 and, with two
+// streams, the next score.  Bounds: >= 8 rows, <= 160 rows (fp32 partial sums per lane).
+int march_seg_rows(const ssimu2_ctx* c, int w, int h, int scale) {
+    if (scale > 0 && c->seg_rows_tail_override > 0) return c->seg_rows_tail_override;
+    if (scale == 0 && c->seg_rows_override > 0) return c->seg_rows_override;
+    int seg;
+    if (scale == 0) {
+        const int nstrips = (w + MW - 1) / MW;
+        int nsegs = (512 + nstrips / 2) / nstrips;
+        if (nsegs < 1) nsegs = 1;
+        seg = (h + nsegs - 1) / nsegs;
+    } else {
+        seg = 48;
+    }
     if (seg < 8) seg = 8;
     if (seg > 160) seg = 160;
     return seg;
 }
 
 int scale_blocks(const ssimu2_ctx* c, const Pyramid& p, int s) {
-    const int seg = march_seg_rows(c, p.w[s], p.h[s]);
+    const int seg = march_seg_rows(c, p.w[s], p.h[s], s);
     return ((p.w[s] + MW - 1) / MW) * ((p.h[s] + seg - 1) / seg);
 }
 
@@ -296,7 +305,7 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
     size_t poff = 0;
     int blocks = 0;
     for (int s = 0; s < p.nscales; ++s) {
-        const int seg = march_seg_rows(c, p.w[s], p.h[s]);
+        const int seg = march_seg_rows(c, p.w[s], p.h[s], s);
         const int nstrips = (p.w[s] + MW - 1) / MW;
         const int nb = nstrips * ((p.h[s] + seg - 1) / seg);
         blocks += nb;
@@ -382,6 +391,7 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     if (!c) return SSIMU2_ERR_OOM;
     c->device = device;
     if (const char* k = getenv("OAVIF_AMD_SEG_ROWS")) c->seg_rows_override = atoi(k);
+    if (const char* k = getenv("OAVIF_AMD_SEG_ROWS_TAIL")) c->seg_rows_tail_override = atoi(k);
 #define CREATE_TRY(call)                                                        \
     do {                                                                        \
         hipError_t e2 = (call);                                                 \
