@@ -74,10 +74,20 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
         return 3
+    # One process per GPU over RCCL (backend "nccl").  OAVIF_BENCH_BACKEND=gloo is a rehearsal
+    # mode for boxes with fewer GPUs than ranks: ranks share devices (local_rank modulo the
+    # device count) and the collectives run on CPU tensors; never used for reported numbers.
+    backend = os.environ.get("OAVIF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import oavif_amd
     from oavif_amd import synth
@@ -127,8 +137,8 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rec = torch.tensor([float(rank), float(score), elapsed], dtype=torch.float64, device="cuda")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    rec = torch.tensor([float(rank), float(score), elapsed], dtype=torch.float64, device=coll_dev)
     if distributed:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         gathered = [torch.zeros_like(rec) for _ in range(world)]
