@@ -214,12 +214,17 @@ def summarize(results: Sequence[ImageResult], wall_s: float, world: int = 1) -> 
 # ---- driver ----------------------------------------------------------------------------------------
 
 def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tuple], rank: int = 0,
-              world: int = 1, gather_device=None, log=None) -> List[ImageResult]:
+              world: int = 1, gather_device=None, log=None, workers: int = 1) -> List[ImageResult]:
     """Process this rank's shard with `encode_fn(index, path) -> (q, score, passes, final_bytes)`
-    and return the gathered, index-sorted results of ALL ranks."""
-    local: List[ImageResult] = []
+    and return the gathered, index-sorted results of ALL ranks.
+
+    `workers` > 1 runs that many images of the shard concurrently in threads: the CPU codec
+    (libavif/aom through Pillow releases the GIL) is 3-4 orders of magnitude slower than the GPU
+    score, so one image at a time leaves both the host cores and the GPU idle.  `encode_fn` must
+    then be thread-safe (one scorer context per thread: contexts are not re-entrant)."""
     errors = {}
-    for i in shard(len(image_files), rank, world):
+
+    def one(i: int) -> ImageResult:
         path = image_files[i]
         res = ImageResult(index=i, image=path.name, orig_bytes=path.stat().st_size)
         t0 = time.perf_counter()
@@ -237,7 +242,15 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
             errors[i] = res.error
             if log:
                 log(res.error)
-        local.append(res)
+        return res
+
+    mine = shard(len(image_files), rank, world)
+    if workers > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            local = list(ex.map(one, mine))
+    else:
+        local = [one(i) for i in mine]
     rec = gather_records(pack_records(local), len(image_files), gather_device)
     names = [p.name for p in image_files]
     results = records_to_results(rec, names)
@@ -259,6 +272,8 @@ def main(argv=None) -> int:
     ap.add_argument("--max-pass", type=int, default=6)        # parse_args.zig:59
     ap.add_argument("--speed", type=int, default=9)           # parse_args.zig:50
     ap.add_argument("--keep", action="store_true", help="keep the generated .avif files")
+    ap.add_argument("--workers", type=int, default=max(1, min(16, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))),
+                    help="images encoded concurrently per rank (threads; one scorer context each)")
     ap.add_argument("--out-dir", default="temp_avif_output")
     args = ap.parse_args(argv)
 
@@ -282,11 +297,17 @@ def main(argv=None) -> int:
     out_dir = Path(args.out_dir)
     out_dir.mkdir(exist_ok=True)
 
+    import threading
+
     from . import Ssimu2
-    scorer = Ssimu2(local_rank)
+    tls = threading.local()
+    all_scorers = []
 
     def encode_fn(_i, path):
-        return encode_image(scorer, path, out_dir / f"{path.stem}.avif", args.score_tgt,
+        if not hasattr(tls, "scorer"):  # one context (HIP stream + scratch) per worker thread
+            tls.scorer = Ssimu2(local_rank)
+            all_scorers.append(tls.scorer)
+        return encode_image(tls.scorer, path, out_dir / f"{path.stem}.avif", args.score_tgt,
                             args.tolerance, args.max_pass, args.speed)
 
     if rank == 0:
@@ -296,7 +317,7 @@ def main(argv=None) -> int:
     t0 = time.perf_counter()
     results = run_batch(files, encode_fn, rank, world,
                         gather_device=torch.device("cuda", local_rank) if world > 1 else None,
-                        log=lambda s: print(s, file=sys.stderr))
+                        log=lambda s: print(s, file=sys.stderr), workers=args.workers)
     wall = time.perf_counter() - t0
     if not args.keep:
         for i in shard(len(files), rank, world):
@@ -308,7 +329,8 @@ def main(argv=None) -> int:
         write_csv(args.output_csv, results)
         print(summarize(results, wall, world))
         print(f"\nResults written to {args.output_csv}")
-    scorer.close()
+    for sc in all_scorers:
+        sc.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

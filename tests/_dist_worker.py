@@ -32,7 +32,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend="gloo")
     files = batch.list_images(images_dir)
-    results = batch.run_batch(files, scripted_encode, rank, world)
+    results = batch.run_batch(files, scripted_encode, rank, world, workers=int(os.environ.get('BATCH_WORKERS', '1')))
     if rank == 0:
         batch.write_csv(out_json + ".csv", results)
         json.dump([[r.index, r.image, r.status, r.q, r.score, r.passes, r.orig_bytes, r.final_bytes]

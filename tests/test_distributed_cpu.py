@@ -34,12 +34,13 @@ def image_dir(tmp_path_factory, hip_lib):
     return d
 
 
-def _run(world, image_dir, out):
+def _run(world, image_dir, out, workers=1):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OAVIF_AMD_NO_TORCH="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OAVIF_AMD_NO_TORCH="0",
+                   BATCH_WORKERS=str(workers))
         procs.append(subprocess.Popen([sys.executable, WORKER, str(image_dir), str(out)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
@@ -67,6 +68,12 @@ def test_world2_gloo_matches_single_process(image_dir, tmp_path):
     ok = [r for r in single if r[2] == "ok"]
     assert len(ok) == 7 and all(1 <= r[5] <= 6 for r in ok)
     assert "Ranks (GPUs): 2" in summary and "7 ok" in summary and "1 errors" in summary
+
+
+def test_worker_threads_do_not_change_results(image_dir, tmp_path):
+    a, _ = _run(2, image_dir, tmp_path / "t1.json", workers=1)
+    b, _ = _run(2, image_dir, tmp_path / "t3.json", workers=3)
+    assert a == b
 
 
 def test_csv_schema_matches_reference_tool(image_dir, tmp_path):

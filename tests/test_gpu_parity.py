@@ -360,3 +360,24 @@ def test_cli_search_end_to_end(scorer, tmp_path, capsys):
     p.write_bytes(pam.write_pam(rgba))
     assert cli.main([str(p), str(tmp_path / "o2.avif")], scorer=scorer) == 0
     assert "Read 320x240, RGBA, 8-bit" in capsys.readouterr().err
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+def test_batch_cli_with_worker_threads(hip_lib, tmp_path):
+    """`python -m oavif_amd.batch` end to end on one GPU: 4 worker threads (one scorer context
+    each) must give the same per-image results as 1."""
+    import csv
+    from PIL import Image
+    from oavif_amd import batch
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(6):
+        Image.fromarray(synth.make_ref(200 + 8 * i, 150, 400 + i)).save(d / f"im{i:02d}.png")
+    rows = {}
+    for workers in (1, 4):
+        out = tmp_path / f"r{workers}.csv"
+        rc = batch.main([str(d), str(out), "--workers", str(workers), "--out-dir", str(tmp_path / f"o{workers}")])
+        assert rc == 0
+        rows[workers] = [(r[0], r[2], r[6], r[7]) for r in list(csv.reader(open(out)))[1:]]
+    assert rows[1] == rows[4]
+    assert len(rows[1]) == 6 and all(r[3] == "ok" for r in rows[1])
