@@ -357,7 +357,7 @@ __device__ __forceinline__ void march_load(MarchRaw& raw, MarchSrc& s, bool row_
 
 // Convert the loaded pixel to positive XYB and store it into ring slot `slot` of frame k
 // (zeros outside the image: the blur is zero padded).
-__device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const float* lut, bool u8,
+__device__ __forceinline__ void march_convert(float (*ring)[3][2][MRW], const float* lut, bool u8,
                                               const MarchRaw& raw, int slot, int k, int col) {
     float rr, gg, bb, v[3];
     if (u8) {
@@ -375,14 +375,14 @@ __device__ __forceinline__ void march_convert(float (*ring)[2][3][MRW], const fl
     linear_to_xyb_pos(rr, gg, bb, v[0], v[1], v[2]);
 #endif
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? v[c] : 0.0f;
+    for (int c = 0; c < 3; ++c) ring[slot][c][k][col] = raw.ok ? v[c] : 0.0f;
 }
 
 // Cached reference: the loaded values already are positive XYB (k_ref_xyb); store them.
-__device__ __forceinline__ void march_store_xyb(float (*ring)[2][3][MRW], const MarchRaw& raw, int slot,
+__device__ __forceinline__ void march_store_xyb(float (*ring)[3][2][MRW], const MarchRaw& raw, int slot,
                                                 int k, int col) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ring[slot][k][c][col] = raw.ok ? __uint_as_float(raw.v[c]) : 0.0f;
+    for (int c = 0; c < 3; ++c) ring[slot][c][k][col] = raw.ok ? __uint_as_float(raw.v[c]) : 0.0f;
 }
 
 // Positive-XYB planes of one frame at one scale (run once per search for the reference, whose
@@ -417,23 +417,23 @@ struct MarchTaps {
     float x[9], y[9], r1, r2;
 };
 
-__device__ __forceinline__ void march_hv_fetch(MarchTaps& m, float (*ring)[2][3][MRW], int t, int ch,
+__device__ __forceinline__ void march_hv_fetch(MarchTaps& m, float (*ring)[3][2][MRW], int t, int ch,
                                                int o) {
     const int slot = t & (RING - 1);
-    const float* px = &ring[slot][0][ch][o];  // staged columns o .. o+8, centre o+4
-    const float* py = &ring[slot][1][ch][o];
+    const float* px = &ring[slot][ch][0][o];  // staged columns o .. o+8, centre o+4
+    const float* py = &ring[slot][ch][1][o];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         m.x[q] = px[q];
         m.y[q] = py[q];
     }
     const int cslot = (t - 4) & (RING - 1);
-    m.r1 = ring[cslot][0][ch][o + RAD];
-    m.r2 = ring[cslot][1][ch][o + RAD];
+    m.r1 = ring[cslot][ch][0][o + RAD];
+    m.r2 = ring[cslot][ch][1][o + RAD];
 }
 
 template <int P>
-__device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&win)[5][9],
+__device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&win)[5][9],
                                               float (&acc)[6], int t, int ch, int o, bool ok,
                                               float w0, float w1, float w2, float w3, float w4) {
     MarchTaps cur;
@@ -502,7 +502,9 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[2][3][MRW], float (&
 
 // launch bound: 3 workgroups of 8 waves per CU = 6 waves per SIMD (<= 80 VGPRs)
 __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
-    __shared__ __attribute__((aligned(16))) float s_ring[RING][2][3][MRW];
+    // [row slot][channel][frame][column]: the x (ref) and y (dist) windows of a channel are 512 B
+    // apart, inside the 8-bit dword offset of one ds_read2 base register
+    __shared__ __attribute__((aligned(16))) float s_ring[RING][3][2][MRW];
     __shared__ float s_lut[256];
     __shared__ double s_part[6][6];
     const int tid = threadIdx.x, lane = tid & 63;
