@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -412,21 +413,32 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     CREATE_TRY(hipEventCreate(&c->ev1));
     CREATE_TRY(hipMalloc(&c->d_result, 110 * sizeof(double)));
     CREATE_TRY(hipHostMalloc(&c->h_result, 110 * sizeof(double), hipHostMallocDefault));
-    DevConst* k = new (std::nothrow) DevConst();
-    if (!k) {
-        ssimu2_ctx_destroy(c);
-        return SSIMU2_ERR_OOM;
+    {
+        // The constant table lives in device memory of this module, one copy per device, shared
+        // by every context on that device: upload it once per device (contexts may be created
+        // from worker threads while other contexts' kernels are running).
+        static std::mutex mu;
+        static bool uploaded[64] = {false};
+        std::lock_guard<std::mutex> lock(mu);
+        if (device >= 64 || !uploaded[device]) {
+            DevConst* k = new (std::nothrow) DevConst();
+            if (!k) {
+                ssimu2_ctx_destroy(c);
+                return SSIMU2_ERR_OOM;
+            }
+            for (int i = 0; i < 256; ++i) {
+                const double v = (double)i / 255.0;
+                k->lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+            }
+            gaussian_taps(1.5, k->taps);
+            k->cbrt_bias = cbrt_repro_host(kOpsinBias);
+            memcpy(k->weights, kWeightsHost, sizeof kWeightsHost);
+            hipError_t ec = hipMemcpyToSymbol(HIP_SYMBOL(c_k), k, sizeof(DevConst));
+            delete k;
+            CREATE_TRY(ec);
+            if (device < 64) uploaded[device] = true;
+        }
     }
-    for (int i = 0; i < 256; ++i) {
-        const double v = (double)i / 255.0;
-        k->lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
-    }
-    gaussian_taps(1.5, k->taps);
-    k->cbrt_bias = cbrt_repro_host(kOpsinBias);
-    memcpy(k->weights, kWeightsHost, sizeof kWeightsHost);
-    hipError_t ec = hipMemcpyToSymbol(HIP_SYMBOL(c_k), k, sizeof(DevConst));
-    delete k;
-    CREATE_TRY(ec);
 #undef CREATE_TRY
     *out_ctx = c;
     return SSIMU2_OK;

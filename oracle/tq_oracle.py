@@ -49,6 +49,12 @@ def quadratic_interpolate(scores, quals, target) -> Optional[float]:  # tq.zig:5
 
 
 def _clamp_round(r: float) -> int:
+    # clamp first: @round(+-inf) is +-inf and clamps to 100 / 0 in the reference; a NaN
+    # interpolant (0/0, unreachable with finite distinct scores) is mapped to 0 like tq.cpp
+    if r != r:
+        return 0
+    if math.isinf(r):
+        return 100 if r > 0 else 0
     return int(min(max(zig_round(r), 0.0), 100.0))
 
 
