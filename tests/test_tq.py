@@ -173,14 +173,16 @@ def score_curves(draw):
     return fn
 
 
-@settings(max_examples=400, deadline=None)
+@settings(max_examples=int(__import__('os').environ.get('TQ_EXAMPLES', 400)), deadline=None,
+          derandomize='TQ_EXAMPLES' not in __import__('os').environ)
 @given(fn=score_curves(), tgt=st.floats(30.0, 100.0), tol=st.floats(1.0, 10.0),
        max_pass=st.integers(1, 12))
 def test_cpp_matches_restatement_on_random_curves(tq, fn, tgt, tol, max_pass):
     run_both(tq, fn, score_tgt=tgt, tolerance=tol, max_pass=max_pass)
 
 
-@settings(max_examples=200, deadline=None)
+@settings(max_examples=int(__import__('os').environ.get('TQ_EXAMPLES', 200)), deadline=None,
+          derandomize='TQ_EXAMPLES' not in __import__('os').environ)
 @given(scores=st.lists(st.floats(-40.0, 100.0), min_size=101, max_size=101),
        tgt=st.floats(30.0, 100.0), max_pass=st.integers(1, 12))
 def test_cpp_matches_restatement_on_arbitrary_tables(tq, scores, tgt, max_pass):
