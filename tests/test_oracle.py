@@ -204,3 +204,23 @@ def test_omp_build_matches_scalar(oracle):
     a = oracle.compute_ssimu2(ref, d, oracle.BLUR_FIR, omp=False)
     b = oracle.compute_ssimu2(ref, d, oracle.BLUR_FIR, omp=True)
     assert abs(a - b) < 1e-9   # only the fp64 reduction order differs
+
+
+def test_scores_agree_with_the_references_own_q_predictor(oracle, golden):
+    """Weak external pin.  tq.zig:40-43 predicts the first probe as q = 6.83 exp(0.0282 tgt): the
+    reference author's empirical fit of quantizer vs SSIMULACRA2 score for libaom.  The oracle's
+    scores of real libaom round trips (Pillow's libavif, other encoder settings than oavif's)
+    must sit near the inverse of that fit -- they would not if the 108 weights, the opsin
+    constants or the final polynomial (typed from the published definition, not verifiable
+    offline) were badly off.  Measured at generation time: q49 -> 72.2, q65 -> 83.0, q86 -> 90.9
+    against the fit's 70, 80, 90."""
+    import math
+    _, meta = golden
+    by_name = {p["name"]: p for p in meta["pairs"]}
+    for q in (49, 65, 86):
+        fit_score = math.log(q / 6.83) / 0.0282
+        got = by_name[f"avif_q{q}"]["score_fir"]
+        assert abs(got - fit_score) < 5.0, (q, got, fit_score)
+    # and the scores are ordered like the quantizers
+    s = [by_name[f"avif_q{q}"]["score_fir"] for q in (20, 49, 65, 86)]
+    assert s == sorted(s)
