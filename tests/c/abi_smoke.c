@@ -1,0 +1,75 @@
+/* Plain C consumer of include/ssimu2_hip.h + include/oavif_tq.h: what a C (or, through the
+ * same symbols, Zig) host does.  Built and run by tests/test_c_consumer.py.
+ *
+ *   abi_smoke W H      -> prints "score <pair> <cached> <identical> passes <n> q <q>"
+ *
+ * Frames are generated here (xorshift), so the Python side can regenerate them and compare
+ * the score with its own call through ctypes. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oavif_tq.h"
+#include "ssimu2_hip.h"
+
+static uint32_t xs = 2463534242u;
+static uint32_t rnd(void) { xs ^= xs << 13; xs ^= xs >> 17; xs ^= xs << 5; return xs; }
+
+typedef struct { const uint8_t* ref; uint32_t w, h; } codec_state;
+
+/* stand-in for encode(q) -> decode: coarser quantisation for lower q */
+static int codec(void* user, uint32_t q, uint8_t* out_rgb, size_t* out_size) {
+    codec_state* s = (codec_state*)user;
+    const int step = 1 + (int)(100 - q) / 4;
+    const size_t n = (size_t)s->w * s->h * 3;
+    for (size_t i = 0; i < n; ++i) {
+        int v = (s->ref[i] / step) * step + step / 2;
+        out_rgb[i] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    *out_size = 1000 + 10 * q;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t w = argc > 1 ? (uint32_t)atoi(argv[1]) : 320, h = argc > 2 ? (uint32_t)atoi(argv[2]) : 200;
+    const size_t n = (size_t)w * h * 3;
+    uint8_t* ref = (uint8_t*)malloc(n);
+    uint8_t* dist = (uint8_t*)malloc(n);
+    if (!ref || !dist) return 2;
+    for (size_t i = 0; i < n; ++i) {  /* smooth-ish field + noise */
+        const size_t px = i / 3, x = px % w, y = px / w;
+        ref[i] = (uint8_t)((x * 3 + y * 2 + (i % 3) * 40 + (rnd() & 15)) & 255);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        int v = ref[i] + (int)(rnd() % 9) - 4;
+        dist[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+    ssimu2_ctx* ctx = NULL;
+    int rc = ssimu2_ctx_create(0, NULL, &ctx);
+    if (rc != SSIMU2_OK) {
+        fprintf(stderr, "ctx_create failed rc=%d: %s\n", rc, ssimu2_last_error(NULL));
+        return rc == SSIMU2_ERR_NO_DEVICE ? 77 : 1;
+    }
+    double pair = 0, cached = 0;
+    if ((rc = ssimu2_score_rgb8(ctx, ref, dist, w, h, 3, &pair))) goto fail;
+    if ((rc = ssimu2_set_reference(ctx, ref, w, h))) goto fail;
+    if ((rc = ssimu2_score_against_reference(ctx, dist, &cached))) goto fail;
+    if (ssimu2_score_rgb8(ctx, ref, dist, w, h, 4, &pair) != SSIMU2_ERR_UNSUPPORTED) { rc = 99; goto fail; }
+
+    oavif_tq_options o;
+    oavif_tq_default_options(&o);
+    oavif_tq_result res;
+    codec_state cs = {ref, w, h};
+    size_t last = 0;
+    if ((rc = oavif_tq_search_hip(&o, ctx, ref, w, h, codec, &cs, &res, &last))) goto fail;
+    printf("score %.12f %.12f %d passes %u q %u last_size %zu version %s\n", pair, cached,
+           pair == cached, res.num_pass, res.q, last, ssimu2_version());
+    ssimu2_ctx_destroy(ctx);
+    free(ref);
+    free(dist);
+    return 0;
+fail:
+    fprintf(stderr, "failed rc=%d: %s\n", rc, ssimu2_last_error(ctx));
+    ssimu2_ctx_destroy(ctx);
+    return 1;
+}
