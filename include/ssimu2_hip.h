@@ -99,6 +99,15 @@ int ssimu2_enqueue_against_reference_device(ssimu2_ctx* ctx, const void* d_dist)
 int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_STATS_PER_SCALE],
                          int* out_num_scales);
 
+/* Parity hook for tests: download one intermediate plane set of the last score / reference.
+   `what`: SSIMU2_DEBUG_LIN_REF / _LIN_DIST = linear-light pyramid level `scale` (1..5) of the
+   reference / distorted frame, SSIMU2_DEBUG_XYB_REF = cached positive-XYB planes of the
+   reference at `scale` (0..5; needs ssimu2_set_reference).  `out` receives 3 planes of
+   w_s*h_s floats; returns SSIMU2_ERR_INVALID_ARG if that level does not exist. */
+enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2 };
+int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
+                          uint32_t* out_w, uint32_t* out_h);
+
 /* Timing hook for bench.py: enqueue `iters` back-to-back scores of the same device pair
    bracketed by HIP events on the ctx stream; returns total device milliseconds. */
 int ssimu2_time_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,

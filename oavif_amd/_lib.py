@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "ssimu2_ctx_create", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
     "ssimu2_set_reference", "ssimu2_score_against_reference", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
-    "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_time_device",
+    "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_debug_download", "ssimu2_time_device",
     "ssimu2_time_stage",
     "ssimu2_version",
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
@@ -104,6 +104,9 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_wait.restype = ci
     L.ssimu2_last_averages.argtypes = [vp, f64p, ctypes.POINTER(ci)]
     L.ssimu2_last_averages.restype = ci
+    L.ssimu2_debug_download.argtypes = [vp, ci, ci, u32, u32, ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.ssimu2_debug_download.restype = ci
     L.ssimu2_time_device.argtypes = [vp, vp, vp, u32, u32, ci, ctypes.POINTER(ctypes.c_float), f64p]
     L.ssimu2_time_device.restype = ci
     L.ssimu2_time_stage.argtypes = [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)]

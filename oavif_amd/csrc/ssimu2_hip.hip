@@ -586,6 +586,31 @@ int ssimu2_last_averages(ssimu2_ctx* c, double* out, int* out_num_scales) {
     return SSIMU2_OK;
 }
 
+int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32_t h, float* out,
+                          uint32_t* out_w, uint32_t* out_h) {
+    if (!c || !out) return SSIMU2_ERR_INVALID_ARG;
+    if (w == 0 || h == 0) return c->fail(SSIMU2_ERR_INVALID_ARG, "zero image dimension");
+    const Pyramid p = make_pyramid(w, h);
+    const float* src = nullptr;
+    if (what == SSIMU2_DEBUG_LIN_REF || what == SSIMU2_DEBUG_LIN_DIST) {
+        if (scale < 1 || scale >= p.nscales || !c->d_lin_ref) return c->fail(SSIMU2_ERR_INVALID_ARG, "no such level");
+        src = (what == SSIMU2_DEBUG_LIN_REF ? c->d_lin_ref : c->d_lin_dist) + p.lin_off[scale];
+    } else if (what == SSIMU2_DEBUG_XYB_REF) {
+        if (scale < 0 || scale >= p.nscales || !c->d_xyb_ref || !c->have_ref || c->ref_w != w || c->ref_h != h)
+            return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference XYB for that level");
+        src = c->d_xyb_ref + xyb_off(p, scale);
+    } else {
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad `what`");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)3 * p.w[scale] * p.h[scale];
+    HIP_TRY(c, hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_w) *out_w = (uint32_t)p.w[scale];
+    if (out_h) *out_h = (uint32_t)p.h[scale];
+    return SSIMU2_OK;
+}
+
 int ssimu2_time_device(ssimu2_ctx* c, const void* d_ref, const void* d_dist, uint32_t w,
                        uint32_t h, int iters, float* out_ms_total, double* out_score) {
     int rc = check_args(c, d_ref, d_dist, w, h);

@@ -149,6 +149,21 @@ class Ssimu2:
             self._raise(rc)
         return ms.value
 
+    def debug_download(self, what: int, scale: int, w: int, h: int) -> np.ndarray:
+        """-> (3, h_s, w_s) float32 planes (see ssimu2_debug_download)."""
+        sw, sh = w, h
+        for _ in range(scale):
+            sw, sh = (sw + 1) // 2, (sh + 1) // 2
+        out = np.empty((3, sh, sw), np.float32)
+        ow, oh = ctypes.c_uint32(), ctypes.c_uint32()
+        rc = self._L.ssimu2_debug_download(self._ctx, what, scale, w, h,
+                                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                           ctypes.byref(ow), ctypes.byref(oh))
+        if rc != 0:
+            self._raise(rc)
+        assert (ow.value, oh.value) == (sw, sh)
+        return out
+
     def last_averages(self):
         """-> ((6, 18) float64 plane averages of the last score, number of scales)."""
         avg = np.zeros(_lib.NUM_SCALES * _lib.STATS_PER_SCALE, np.float64)

@@ -381,3 +381,28 @@ def test_batch_cli_with_worker_threads(hip_lib, tmp_path):
         rows[workers] = [(r[0], r[2], r[6], r[7]) for r in list(csv.reader(open(out)))[1:]]
     assert rows[1] == rows[4]
     assert len(rows[1]) == 6 and all(r[3] == "ok" for r in rows[1])
+
+
+@pytest.mark.parametrize("w,h", [(333, 217), (512, 512), (121, 9)])
+def test_intermediate_planes_are_bit_identical(scorer, oracle, w, h):
+    """Stage-by-stage parity (bit-exact, as for integer work): the linear-light pyramid of both
+    frames and the cached positive-XYB planes of the reference equal the oracle's planes bit for
+    bit -- the arithmetic contract (explicit fmaf order, reproducible cube root) holds per pixel,
+    so everything upstream of the blur is identical and the blur itself is the same fmaf chain."""
+    ref = synth.make_ref(w, h, 11 * w + h)
+    dist = synth.distort(ref, "noise", 2, seed=1)
+    lut = oracle.srgb_lut()
+    lin = {0: [np.ascontiguousarray(lut[f].transpose(2, 0, 1)) for f in (ref, dist)]}
+    scorer.compute_ssimu2(ref, dist)
+    _, ns = scorer.last_averages()
+    for s in range(1, ns):
+        lin[s] = [oracle.downsample2(a) for a in lin[s - 1]]
+        got_r = scorer.debug_download(0, s, w, h)
+        got_d = scorer.debug_download(1, s, w, h)
+        assert np.array_equal(got_r.view(np.uint32), lin[s][0].view(np.uint32)), s
+        assert np.array_equal(got_d.view(np.uint32), lin[s][1].view(np.uint32)), s
+    scorer.set_reference(ref)
+    for s in range(ns):
+        got = scorer.debug_download(2, s, w, h)
+        exp = oracle.linear_to_xyb(lin[s][0])
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), s
