@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
 // `seg` output rows, one image row per step.
 //   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128), both frames.  Each
 //     step they convert one input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive XYB)
-//     into an LDS ring of raw rows, two barrier groups ahead of the blur waves; their global
+//     into an LDS ring of raw rows, one barrier group ahead of the blur waves; their global
 //     loads run one more group ahead, so HBM latency is off the critical path.
 //   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
 //     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
@@ -293,7 +293,11 @@ constexpr int MW = 120;        // output columns per strip
 constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 waves per frame
 constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
 constexpr int RING = 16;       // raw-row ring depth (power of two >= 13: rows t-4 .. t+8)
-constexpr int AHEAD = 2 * 3;   // rows the converters run ahead of the blur waves (2 groups)
+#ifdef EXP_AHEAD
+constexpr int AHEAD = EXP_AHEAD;
+#else
+constexpr int AHEAD = 3;       // rows the converters run ahead of the blur waves (1 group)
+#endif
 constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
 constexpr int MARCH_THREADS = 512;
 constexpr int CONV_WAVES = 2;  // each converter lane handles one staged column of BOTH frames
@@ -533,8 +537,6 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     const float w0 = c_k.taps[0], w1 = c_k.taps[1], w2 = c_k.taps[2], w3 = c_k.taps[3],
                 w4 = c_k.taps[4];
     const bool is_conv = wave < CONV_WAVES;
-    // (measured: raising the blur waves' issue priority with s_setprio makes the converters
-    // the laggards and costs 7 %; both roles run at default priority)
     // blur state (fp32 sums: at most seg <= 160 terms per lane before the fp64 reduce)
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int hw = wave - CONV_WAVES;
@@ -544,12 +546,17 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     const bool ok = x0 + o < w;
 
     // Input row j (= image row y0-4+j) lives in ring slot j & (RING-1).  While the blur waves
-    // consume rows 3I..3I+2 the converters fill rows 3I+6..3I+8 (two groups ahead, so a blur
-    // wave may read one row past its group).  The two roles run separate loops with the same
+    // consume rows 3I..3I+2 the converters fill rows 3I+AHEAD..3I+AHEAD+2.  The two roles run separate loops with the same
     // number of barriers (one per group of GROUP rows), so each gets its own register
     // allocation instead of carrying the other role's state.
     const int ngroups = (steps + GROUP - 1) / GROUP;
     if (is_conv) {
+        // The converter waves carry the heavier per-row stream on their SIMDs (~225 vs ~180
+        // instructions); a static issue-priority bump lets them keep pace (measured: -7 %).
+#ifndef EXP_CONV_PRIO
+#define EXP_CONV_PRIO 1
+#endif
+        __builtin_amdgcn_s_setprio(EXP_CONV_PRIO);
         const int col = (wave << 6) + lane;  // staged column; this lane converts both frames
         const int gx = x0 - RAD + col;
         const bool col_ok = gx >= 0 && gx < w;
