@@ -46,6 +46,31 @@ ALGO_BYTES_PER_PX_MARCH = 77.97
 ALGO_BYTES_PER_PX_BLUR = 31.99
 
 
+def usable_cores() -> int:
+    """Host threads this process may really use: the cgroup CPU quota if there is one, else the
+    affinity mask, capped at 32 (the GPU box gives a 1-GPU job ~16 cores of a 256-thread host;
+    oversubscribing OpenMP 16x makes the CPU baseline 5x slower than it is)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 32))
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,12 +260,31 @@ def main() -> int:
         out["search_pass_note"] = ("pageable host dist -> H2D -> score -> D2H score; excludes the "
                                    "CPU libaom encode / dav1d decode of the pass")
 
+        # ---- one REAL search pass end to end (tq.zig:21-38): CPU encode -> CPU decode -> upload
+        # -> GPU score, with Pillow's libavif (aom speed 9, YUV444) standing in for oavif's ----
+        if world == 1 and synth.have_avif() and not args.no_cpu_baseline:
+            try:
+                t_e = time.perf_counter()
+                data = synth.avif_encode(ref, 65, speed=9)
+                t_d = time.perf_counter()
+                dec = synth.avif_decode(data)
+                t_s = time.perf_counter()
+                real_score = scorer.score_against_reference(dec)
+                t_x = time.perf_counter()
+                out["search_pass_end_to_end_4k"] = {
+                    "encode_ms": round((t_d - t_e) * 1e3, 1), "decode_ms": round((t_s - t_d) * 1e3, 1),
+                    "upload_plus_score_ms": round((t_x - t_s) * 1e3, 3), "q": 65,
+                    "score": round(real_score, 4), "avif_bytes": len(data),
+                    "note": "the GPU share of a pass is the last term; libaom encode dominates"}
+            except Exception as e:  # the codec is not part of the measured path
+                out["search_pass_end_to_end_4k"] = {"error": str(e)}
+
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ssimu2_oracle as orc
             orc.build()
-            cores = os.cpu_count() or 1
-            os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()
+            os.environ["OMP_NUM_THREADS"] = str(cores)
             orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)  # spin up
             tc = time.perf_counter()
             reps = 0
