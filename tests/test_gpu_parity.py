@@ -406,3 +406,36 @@ def test_intermediate_planes_are_bit_identical(scorer, oracle, w, h):
         got = scorer.debug_download(2, s, w, h)
         exp = oracle.linear_to_xyb(lin[s][0])
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), s
+
+
+def test_caller_owned_stream(hip_lib):
+    """ssimu2_ctx_create(device, hipStream_t): all work goes on the caller's stream."""
+    import torch
+    import oavif_amd
+    ref = synth.make_ref(300, 200, 9)
+    dist = synth.distort(ref, "blockq", 1)
+    with oavif_amd.Ssimu2(0) as own:
+        expect = own.compute_ssimu2(ref, dist)
+    st = torch.cuda.Stream()
+    with oavif_amd.Ssimu2(0, stream=st.cuda_stream) as s:
+        assert s.compute_ssimu2(ref, dist) == expect
+        t_ref = torch.from_numpy(ref).cuda().contiguous()
+        t_d = torch.from_numpy(dist).cuda().contiguous()
+        torch.cuda.synchronize()
+        s.enqueue_device(t_ref.data_ptr(), t_d.data_ptr(), 300, 200)
+        st.synchronize()                      # the caller's own synchronisation covers the work
+        assert s.wait() == expect
+
+
+@pytest.mark.parametrize("seg,tail", [(8, 8), (13, 21), (47, 160), (160, 9), (1, 1)])
+def test_any_segment_length_gives_the_same_score(hip_lib, scorer, seg, tail, monkeypatch):
+    """The per-workgroup row ranges (OAVIF_AMD_SEG_ROWS*) only regroup the fp64 partial sums."""
+    import oavif_amd
+    ref = synth.make_ref(517, 391, 19)
+    dist = synth.distort(ref, "noise", 2, seed=4)
+    expect = scorer.compute_ssimu2(ref, dist)
+    monkeypatch.setenv("OAVIF_AMD_SEG_ROWS", str(seg))
+    monkeypatch.setenv("OAVIF_AMD_SEG_ROWS_TAIL", str(tail))
+    with oavif_amd.Ssimu2(0) as s:
+        got = s.compute_ssimu2(ref, dist)
+    assert abs(got - expect) < 1e-7
