@@ -196,27 +196,25 @@ Pyramid make_pyramid(uint32_t w, uint32_t h) {
 // rows of conversion and horizontal blur, so longer is cheaper; shorter gives more workgroups
 // to balance.  Measured on MI355X at 4K (scripts/gpu_sweep2.sh): the full-resolution scale is
 // best at ~512 workgroups (two thirds of the 768 resident slots, 6 % halo), the smaller scales
-// at a fixed ~48 rows -- their few, long workgroups overlap the tail of scale 0 and, with two
+// at ~48 rows -- their few, long workgroups overlap the tail of scale 0 and, with two
 // streams, the next score.  Bounds: >= 8 rows, <= 160 rows (fp32 partial sums per lane).
-int march_seg_rows(const ssimu2_ctx* c, int w, int h, int scale) {
+int march_seg_rows(const ssimu2_ctx* c, const Pyramid& p, int scale) {
     if (scale > 0 && c->seg_rows_tail_override > 0) return c->seg_rows_tail_override;
     if (scale == 0 && c->seg_rows_override > 0) return c->seg_rows_override;
-    int seg;
-    if (scale == 0) {
-        const int nstrips = (w + MW - 1) / MW;
-        int nsegs = (512 + nstrips / 2) / nstrips;
-        if (nsegs < 1) nsegs = 1;
-        seg = (h + nsegs - 1) / nsegs;
-    } else {
-        seg = 48;
-    }
+    const int nstrips = (p.w[0] + MW - 1) / MW;
+    int nsegs = (512 + nstrips / 2) / nstrips;
+    if (nsegs < 1) nsegs = 1;
+    int seg = (p.h[0] + nsegs - 1) / nsegs;  // full-resolution scale: ~512 workgroups
     if (seg < 8) seg = 8;
     if (seg > 160) seg = 160;
+    // smaller scales: 48 rows, but never longer than the full-resolution segments, or their
+    // workgroups would outlast scale 0's on small frames
+    if (scale > 0 && seg > 48) seg = 48;
     return seg;
 }
 
 int scale_blocks(const ssimu2_ctx* c, const Pyramid& p, int s) {
-    const int seg = march_seg_rows(c, p.w[s], p.h[s], s);
+    const int seg = march_seg_rows(c, p, s);
     return ((p.w[s] + MW - 1) / MW) * ((p.h[s] + seg - 1) / seg);
 }
 
@@ -306,7 +304,7 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
     size_t poff = 0;
     int blocks = 0;
     for (int s = 0; s < p.nscales; ++s) {
-        const int seg = march_seg_rows(c, p.w[s], p.h[s], s);
+        const int seg = march_seg_rows(c, p, s);
         const int nstrips = (p.w[s] + MW - 1) / MW;
         const int nb = nstrips * ((p.h[s] + seg - 1) / seg);
         blocks += nb;
