@@ -53,6 +53,8 @@
 #define OR_NUM_SCALES 6
 #define OR_BLUR_IIR 0
 #define OR_BLUR_FIR 1
+#define OR_BLUR_EXACT 2 /* the same 9-tap operator accumulated in fp64, result rounded to fp32:
+                          what both fp32 forms approximate (evidence for DESIGN.md 2.1) */
 
 /* ---- constants of the published algorithm ------------------------------------- */
 
@@ -238,6 +240,32 @@ static void fir_line_prod(const or_gauss* rg, const float* a, const float* b, pt
    see fir_line_prod; IIR mode: the published form, product plane materialised first). */
 static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const float* b, size_t w,
                             size_t h, float* prod_tmp, float* tmp, float* out);
+
+/* fp64 evaluation of the 9-tap operator on a strided line of doubles */
+static void fir_line_f64(const or_gauss* rg, const double* in, ptrdiff_t n_in, ptrdiff_t stride_in,
+                         double* out, ptrdiff_t stride_out) {
+#define AT(i) (((i) >= 0 && (i) < n_in) ? in[(i) * stride_in] : 0.0)
+    for (ptrdiff_t n = 0; n < n_in; ++n) {
+        double acc = rg->fird[0] * AT(n);
+        for (int d = 1; d <= 4; ++d) acc += rg->fird[d] * (AT(n - d) + AT(n + d));
+        out[n * stride_out] = acc;
+    }
+#undef AT
+}
+
+/* 2-D blur in fp64 of an fp32 plane (or of the product a*b when b != NULL), rounded once */
+static void blur_plane_exact(const or_gauss* rg, const float* a, const float* b, size_t w, size_t h,
+                             float* out) {
+    const size_t n = w * h;
+    double* p = (double*)malloc(sizeof(double) * n);
+    double* t = (double*)malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; ++i) p[i] = b ? (double)a[i] * (double)b[i] : (double)a[i];
+    for (size_t y = 0; y < h; ++y) fir_line_f64(rg, p + y * w, w, 1, t + y * w, 1);
+    for (size_t x = 0; x < w; ++x) fir_line_f64(rg, t + x, h, w, p + x, w);
+    for (size_t i = 0; i < n; ++i) out[i] = (float)p[i];
+    free(p);
+    free(t);
+}
 
 /* 2-D blur of one w*h plane: horizontal into tmp, vertical into out. */
 static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, size_t h,
@@ -512,6 +540,14 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
         for (int c = 0; c < 3; ++c) {
             const float *a = img1 + c * n, *b = img2 + c * n;
             float* m = mul + c * n;
+            if (blur_mode == OR_BLUR_EXACT) {
+                blur_plane_exact(&rg, a, a, cw, ch, s11 + c * n);
+                blur_plane_exact(&rg, b, b, cw, ch, s22 + c * n);
+                blur_plane_exact(&rg, a, b, cw, ch, s12 + c * n);
+                blur_plane_exact(&rg, a, NULL, cw, ch, mu1 + c * n);
+                blur_plane_exact(&rg, b, NULL, cw, ch, mu2 + c * n);
+                continue;
+            }
             blur_plane_prod(&rg, blur_mode, a, a, cw, ch, m, tmp, s11 + c * n);
             blur_plane_prod(&rg, blur_mode, b, b, cw, ch, m, tmp, s22 + c * n);
             blur_plane_prod(&rg, blur_mode, a, b, cw, ch, m, tmp, s12 + c * n);

@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BLUR_IIR = 0  # libjxl recursive Gaussian, as published
 BLUR_FIR = 1  # its exact-arithmetic equivalent, 9-tap zero-padded FIR
+BLUR_EXACT = 2  # the same operator accumulated in fp64 (what both fp32 forms approximate)
 
 _libs: dict[bool, ctypes.CDLL] = {}
 
