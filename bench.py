@@ -279,6 +279,36 @@ def main() -> int:
             except Exception as e:  # the codec is not part of the measured path
                 out["search_pass_end_to_end_4k"] = {"error": str(e)}
 
+        # ---- quantizer match vs CPU: the same search (tq.zig:124-210) driven by the HIP scorer
+        # and by the CPU oracle, same CPU codec, small frames so the oracle stays quick ---------
+        if world == 1 and synth.have_avif() and not args.no_cpu_baseline:
+            try:
+                from oavif_amd import tq as _tq
+                from oracle import ssimu2_oracle as _orc
+                from oracle import tq_oracle as _tqo
+                _orc.build()
+                same, worst, cases = True, 0.0, []
+                for seed, tgt in ((0, 80.0), (1, 65.0), (2, 90.0)):
+                    r0 = synth.make_ref(384, 256, 500 + seed)
+                    cache = {}
+
+                    def codec(q, r0=r0, cache=cache):
+                        if q not in cache:
+                            cache[q] = synth.avif_roundtrip(r0, q, speed=9)
+                        return cache[q]
+                    g = _tq.search_hip(scorer, r0, codec, score_tgt=tgt)
+                    cpu = _tqo.find_target_quality(
+                        lambda q: _orc.compute_ssimu2(r0, codec(q)[0], _orc.BLUR_FIR), score_tgt=tgt)
+                    ok = ([q for q, _ in g.history] == [q for q, _ in cpu.history]) and g.q == cpu.q
+                    same = same and ok
+                    worst = max([worst] + [abs(a[1] - b[1]) for a, b in zip(g.history, cpu.history)])
+                    cases.append({"target": tgt, "q_hip": g.q, "q_cpu": cpu.q, "passes": g.num_pass})
+                out["quantizer_match_vs_cpu"] = {"identical": bool(same), "max_abs_dscore": worst,
+                                                 "cases": cases,
+                                                 "cpu": "oracle/ssimu2_oracle.c (fssimu2 parity unpinned)"}
+            except Exception as e:
+                out["quantizer_match_vs_cpu"] = {"error": str(e)}
+
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ssimu2_oracle as orc
