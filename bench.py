@@ -313,8 +313,7 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ssimu2_oracle as orc
             orc.build()
-            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()
-            os.environ["OMP_NUM_THREADS"] = str(cores)
+            cores = orc.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores())
             orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)  # spin up
             tc = time.perf_counter()
             reps = 0

@@ -49,6 +49,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define OR_NUM_SCALES 6
 #define OR_BLUR_IIR 0
@@ -480,6 +483,18 @@ double or_score_from_averages(const double* avg /* nscales*18 */, int nscales) {
     if (ssim > 0.0) ssim = 100.0 - 10.0 * pow(ssim, 0.6276336467831387);
     else ssim = 100.0;
     return ssim;
+}
+
+/* thread count of the OpenMP build (the environment variable is read only once per process,
+   and another library may have initialised the OpenMP runtime first) */
+int or_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 void or_weights(double* out108) { memcpy(out108, kWeights, sizeof(kWeights)); }

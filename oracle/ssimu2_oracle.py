@@ -56,6 +56,8 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
         lib.or_score_from_averages.restype = ctypes.c_double
         lib.or_cbrtf.argtypes = [ctypes.c_float]
         lib.or_cbrtf.restype = ctypes.c_float
+        lib.or_set_num_threads.argtypes = [ctypes.c_int]
+        lib.or_set_num_threads.restype = ctypes.c_int
         lib.or_weights.argtypes = [f64p]
         lib.or_weights.restype = None
         _libs[omp] = lib
@@ -149,3 +151,8 @@ def weights() -> np.ndarray:
 
 def cbrtf(x: float) -> float:
     return float(_lib().or_cbrtf(float(x)))
+
+
+def set_num_threads(n: int) -> int:
+    """Thread count of the OpenMP build; returns the count in effect."""
+    return int(_lib(True).or_set_num_threads(int(n)))
