@@ -665,8 +665,16 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __re
     const int scale = item / kStats, stat = item - scale * kStats;
     const bool live = item < kNumScales * kStats && scale < fa.nscales;
     if (live) {
+        // each lane sums runs of 8 consecutive partials: the 8 loads of a run are independent,
+        // so the loop is 8x shorter than one dependent load + add per partial
         const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
-        for (int b = sub; b < fa.nblocks[scale]; b += 8) v += p[b];
+        const int nb = fa.nblocks[scale];
+        for (int b = sub * 8; b < nb; b += 64) {
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = b + k < nb ? p[b + k] : 0.0;
+            v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
     }
     v += __shfl_down(v, 4, 8);
     v += __shfl_down(v, 2, 8);
