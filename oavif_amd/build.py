@@ -38,14 +38,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
-           "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
-           "-Wall", "-Wno-unused-function", "-o", LIB_PATH]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    # several ranks of one job may get here at once on a fresh checkout: one compiles (file
+    # lock), the others wait and find the library up to date; the .so appears atomically
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB_PATH
+        tmp = LIB_PATH + f".tmp{os.getpid()}"
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
+               "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
+               "-Wall", "-Wno-unused-function", "-o", tmp]
+        cmd += [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
     return LIB_PATH
 
 
