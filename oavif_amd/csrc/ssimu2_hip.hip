@@ -98,15 +98,17 @@ float cbrt_repro_host(float x) {
     if (!(x > 0.0f)) return 0.0f;
     uint32_t i;
     memcpy(&i, &x, 4);
-    i = 0x54A2FA8Cu - i / 3u;
+    i = 0x54A21D2Au - i / 3u;
     float y;
     memcpy(&y, &i, 4);
-    for (int k = 0; k < 2; ++k) {
-        float t = x * y;
-        t = t * y;
-        t = t * y;
-        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
-    }
+    float t = x * y;
+    t = t * y;
+    t = t * y;
+    const float e = 1.0f - t;
+    float p = fmaf(e, 14.0f / 81.0f, 2.0f / 9.0f);
+    p = fmaf(p, e, 1.0f / 3.0f);
+    p = p * e;
+    y = fmaf(y, p, y);
     const float y2 = y * y;
     float c = x * y2;
     const float r = fmaf(c * c, c, -x);

@@ -333,25 +333,28 @@ static void rgb8_to_linear(const uint8_t* rgb, size_t n, float* lin /* 3*n */) {
 }
 
 /* Cube root from IEEE mul/fma only (no libm, no division), so that a GPU evaluating the
-   same sequence returns the same bits: bit-trick seed for x^(-1/3), two Newton steps
-   y <- y (4/3 - x y^3 / 3), c = x y^2, one Newton step on c with the residual from one
-   fma.  Measured against cbrt() in fp64 over [0.0037, 1.01] and 1e-30..1e30: max error
-   0.76 ulp, 91 % correctly rounded (tests/test_oracle.py) -- the same class as libm's
-   cbrtf.  Why it matters: the SSIM map cancels (sigma terms ~1e-5 out of values ~0.25), so
-   a 1-ulp difference here moves the score by ~1e-3 (DESIGN.md "Arithmetic contract"). */
+   same sequence returns the same bits: bit-trick seed for y = x^(-1/3) (3 % off), one
+   third-order step y <- y (1 + e/3 + 2e^2/9 + 14e^3/81), e = 1 - x y^3 (the series of
+   (1-e)^(-1/3)), c = x y^2, one Newton step on c with the residual from one fma.  17
+   operations.  Measured against cbrt() in fp64 over [0.0037, 1.01] and 1e-30..1e30: max error
+   0.76 ulp, 91 % correctly rounded (tests/test_oracle.py) -- the same class as libm's cbrtf.
+   Why it matters: the SSIM map cancels (sigma terms ~1e-5 out of values ~0.25), so a 1-ulp
+   difference here moves the score by ~1e-3 (DESIGN.md "Arithmetic contract"). */
 float or_cbrtf(float x) {
     if (!(x > 0.0f)) return 0.0f;
     uint32_t i;
     memcpy(&i, &x, 4);
-    i = 0x54A2FA8Cu - i / 3u;
+    i = 0x54A21D2Au - i / 3u;
     float y;
     memcpy(&y, &i, 4);
-    for (int k = 0; k < 2; ++k) {
-        float t = x * y;
-        t = t * y;
-        t = t * y;
-        y = y * fmaf(-1.0f / 3.0f, t, 4.0f / 3.0f);
-    }
+    float t = x * y;
+    t = t * y;
+    t = t * y;
+    const float e = 1.0f - t;
+    float p = fmaf(e, 14.0f / 81.0f, 2.0f / 9.0f);
+    p = fmaf(p, e, 1.0f / 3.0f);
+    p = p * e;
+    y = fmaf(y, p, y);
     const float y2 = y * y;
     float c = x * y2;
     const float r = fmaf(c * c, c, -x);

@@ -228,14 +228,18 @@ def test_scores_agree_with_the_references_own_q_predictor(oracle, golden):
 
 def test_fp32_fir_is_closer_to_the_exact_operator_than_the_fp32_recursion(oracle, golden):
     """Evidence for choosing the FIR form: with the blur accumulated in fp64
-    (BLUR_EXACT) as the yardstick, the fp32 FIR lands within a few 1e-3 of it on every fixture,
-    the fp32 recursion 3x to 100x further away."""
+    (BLUR_EXACT) as the yardstick, the fp32 FIR lands within a few 1e-3 of it on every fixture;
+    the fp32 recursion's rounding noise is random, so fixture by fixture it can land anywhere,
+    but over the set it is an order of magnitude further away."""
     arrays, meta = golden
     ref = arrays["ref"]
+    d_fir, d_iir = [], []
     for p in meta["pairs"]:
+        if p["name"] == "identical":
+            continue
         exact = oracle.compute_ssimu2(ref, arrays[p["name"]], oracle.BLUR_EXACT)
-        d_fir = abs(p["score_fir"] - exact)
-        d_iir = abs(p["score_iir"] - exact)
-        assert d_fir < 5e-3, (p["name"], d_fir)
-        if p["name"] != "identical":
-            assert d_iir > 2.5 * d_fir, (p["name"], d_fir, d_iir)
+        d_fir.append(abs(p["score_fir"] - exact))
+        d_iir.append(abs(p["score_iir"] - exact))
+    assert max(d_fir) < 5e-3, d_fir
+    assert np.mean(d_iir) > 8 * np.mean(d_fir), (d_fir, d_iir)
+    assert max(d_iir) > 20 * max(d_fir), (d_fir, d_iir)
