@@ -219,6 +219,22 @@ def main() -> int:
                            "model": "SURVEY 8(d) W-model minus the pyramid writes: 77.97 B/px",
                            "blur_pyramid_frac_if_all_time_were_blur": round(
                                ALGO_BYTES_PER_PX_BLUR * w * h / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # what actually bounds the kernel: VALU issue (counters from profiles/valu.json)
+        vp = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vp) and (w, h) == (W, H):
+            try:
+                vj = json.load(open(vp))
+                rate = vj["march_valu_wave_instructions_per_launch"] / (k_ms * 1e6) / vj["simds"]
+                out["valu_roofline"] = {
+                    "kernel": "k_march", "achieved": round(rate, 4),
+                    "peak": vj["peak_valu_wave_instructions_per_ns_per_simd"],
+                    "unit": "VALU wave-instructions/ns/SIMD",
+                    "frac": round(rate / vj["peak_valu_wave_instructions_per_ns_per_simd"], 4),
+                    "valu_wave_instructions": vj["march_valu_wave_instructions_per_launch"],
+                    "note": "instruction count from PMC SQ_INSTS_VALU (profiles/), time live; "
+                            "HBM traffic is 28 % of the algorithmic bytes, so HBM is not the limiter"}
+            except Exception:
+                pass
         out["stages_ms"] = {"pyramid": round(pyr_ms, 5), "march": round(k_ms, 5),
                             "finalize": round(fin_ms, 5)}
         # whole-score view (all kernels of one score, W-model 85.97 B/px)
