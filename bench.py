@@ -275,6 +275,26 @@ def main() -> int:
         out["ms_per_search_pass_4k_gpu_side"] = round((time.perf_counter() - tt) / n_pass * 1e3, 4)
         out["search_pass_note"] = ("pageable host dist -> H2D -> score -> D2H score; excludes the "
                                    "CPU libaom encode / dav1d decode of the pass")
+        # decoded-frame hand-off: libavif's RGBA rows scored as they are
+        # (alpha dropped on the device) vs the reference's CPU copy loop (io.zig:654-663, timed
+        # through the oracle's restatement) followed by the tight-RGB pass above
+        rgba = np.concatenate([dst, np.full((H, W, 1), 255, np.uint8)], axis=2)
+        s_rgba = scorer.score_decoded_against_reference(rgba)
+        tt = time.perf_counter()
+        for _ in range(n_pass):
+            scorer.score_decoded_against_reference(rgba)
+        ms_rgba = (time.perf_counter() - tt) / n_pass * 1e3
+        handoff = {"ms_per_pass_rgba_strided_gpu_side": round(ms_rgba, 4),
+                   "bit_identical_to_tight_rgb": bool(s_rgba == scores[0])}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ssimu2_oracle as orc_copy  # checker / CPU timing only
+            orc_copy.build()
+            orc_copy.copy_rgb_pixels(rgba)
+            tt = time.perf_counter()
+            for _ in range(3):
+                orc_copy.copy_rgb_pixels(rgba)
+            handoff["ms_cpu_copy_loop_io_zig_654"] = round((time.perf_counter() - tt) / 3 * 1e3, 3)
+        out["decoded_frame_handoff_4k"] = handoff
 
         # ---- one REAL search pass end to end (tq.zig:21-38): CPU encode -> CPU decode -> upload
         # -> GPU score, with Pillow's libavif (aom speed 9, YUV444) standing in for oavif's ----

@@ -75,6 +75,19 @@ int ssimu2_score_rgb8(ssimu2_ctx* ctx, const uint8_t* ref, const uint8_t* dist, 
 int ssimu2_set_reference(ssimu2_ctx* ctx, const uint8_t* ref, uint32_t w, uint32_t h);
 int ssimu2_score_against_reference(ssimu2_ctx* ctx, const uint8_t* dist, double* out_score);
 
+/* Decoded-frame hand-off (replaces the copy loop of io.decodeAvifToRgb, io.zig:638-666, together
+   with tq.zig:37).  The reference decodes a probe into libavif's avifRGBImage -- 8 bits per
+   channel (rgb.depth = 8, io.zig:470-471), RGB or RGBA (io.zig:473), rows `row_bytes` apart --
+   and then copies it pixel by pixel on the CPU into a tight RGB buffer for the scorer
+   (io.zig:654-663).  This entry point takes the avifRGBImage buffer as it is
+   (`pixels` = rgb.pixels, `row_bytes` = rgb.rowBytes, `channels` = 3 or 4), uploads it and drops
+   the alpha bytes / row padding on the device, then scores it against the cached reference.
+   The score is bit-identical to ssimu2_score_against_reference on the CPU-copied frame.
+   Errors: SSIMU2_ERR_UNSUPPORTED for channels other than 3 or 4, SSIMU2_ERR_INVALID_ARG for
+   row_bytes < w * channels. */
+int ssimu2_score_against_reference_strided(ssimu2_ctx* ctx, const uint8_t* pixels,
+                                           uint32_t row_bytes, uint32_t channels, double* out_score);
+
 /* Device-resident variants: `d_ref` / `d_dist` are device pointers (same RGB8 layout)
    valid on the ctx's device.  _enqueue only enqueues on the ctx stream and returns;
    ssimu2_wait blocks until the enqueued score is done and returns it.  Used by the

@@ -27,7 +27,8 @@ TQ_MAX_PASS = 12
 # every symbol the headers declare; tests/test_abi.py checks the .so exports all of them
 EXPORTED_SYMBOLS = (
     "ssimu2_ctx_create", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
-    "ssimu2_set_reference", "ssimu2_score_against_reference", "ssimu2_set_reference_device",
+    "ssimu2_set_reference", "ssimu2_score_against_reference",
+    "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
     "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_debug_download", "ssimu2_time_device",
     "ssimu2_time_stage",
@@ -92,6 +93,8 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_set_reference.restype = ci
     L.ssimu2_score_against_reference.argtypes = [vp, u8p, f64p]
     L.ssimu2_score_against_reference.restype = ci
+    L.ssimu2_score_against_reference_strided.argtypes = [vp, u8p, u32, u32, f64p]
+    L.ssimu2_score_against_reference_strided.restype = ci
     L.ssimu2_set_reference_device.argtypes = [vp, vp, u32, u32]
     L.ssimu2_set_reference_device.restype = ci
     L.ssimu2_enqueue_against_reference_device.argtypes = [vp, vp]

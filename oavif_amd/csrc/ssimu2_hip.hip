@@ -133,6 +133,8 @@ struct ssimu2_ctx {
     float* d_lin_ref = nullptr;   // scales 1..5 packed
     float* d_lin_dist = nullptr;
     float* d_xyb_ref = nullptr;   // cached positive-XYB planes of the reference, all scales
+    uint8_t* d_stage = nullptr;   // decoded avifRGBImage as uploaded (RGBA / padded rows)
+    size_t cap_stage = 0;
     size_t cap_xyb = 0;
     double* d_partials = nullptr;
     double* d_result = nullptr;   // 110 doubles
@@ -235,6 +237,9 @@ void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_xyb_ref);
     c->d_xyb_ref = nullptr;
     c->cap_xyb = 0;
+    (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->cap_stage = 0;
     c->d_ref_u8 = c->d_dist_u8 = nullptr;
     c->d_lin_ref = c->d_lin_dist = nullptr;
     c->d_partials = nullptr;
@@ -571,6 +576,43 @@ int ssimu2_score_against_reference(ssimu2_ctx* c, const uint8_t* dist, double* o
     const size_t bytes = (size_t)c->ref_w * c->ref_h * 3;
     HIP_TRY(c, hipMemcpyAsync(c->d_dist_u8, dist, bytes, hipMemcpyHostToDevice, c->stream));
     int rc = enqueue_score(c, c->d_ref_u8, c->d_dist_u8, c->ref_w, c->ref_h, true);
+    if (rc) return rc;
+    return ssimu2_wait(c, out_score);
+}
+
+int ssimu2_score_against_reference_strided(ssimu2_ctx* c, const uint8_t* pixels, uint32_t row_bytes,
+                                           uint32_t channels, double* out_score) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!c->have_ref) return c->fail(SSIMU2_ERR_NO_REFERENCE, "no reference set");
+    if (!pixels || !out_score) return c->fail(SSIMU2_ERR_INVALID_ARG, "null pointer");
+    if (channels != 3 && channels != 4)
+        return c->fail(SSIMU2_ERR_UNSUPPORTED, "channels must be 3 (RGB) or 4 (RGBA)");
+    const uint32_t w = c->ref_w, h = c->ref_h;
+    if ((uint64_t)row_bytes < (uint64_t)w * channels)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "row_bytes smaller than one row of pixels");
+    if (channels == 3 && row_bytes == w * 3)  // already the scorer's layout
+        return ssimu2_score_against_reference(c, pixels, out_score);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the last row needs only its pixels, not its padding (libavif allocates rowBytes * height,
+    // a cropped view of a larger buffer may not)
+    const size_t bytes = (size_t)row_bytes * (h - 1) + (size_t)w * channels;
+    if (bytes > c->cap_stage) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_stage);
+        c->d_stage = nullptr;
+        c->cap_stage = 0;
+        hipError_t e = hipMalloc(&c->d_stage, bytes + 16);
+        if (e != hipSuccess) return c->fail(SSIMU2_ERR_OOM, "hipMalloc(staging frame)", e);
+        c->cap_stage = bytes;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage, pixels, bytes, hipMemcpyHostToDevice, c->stream));
+    if (channels == 4 && w % 4 == 0 && row_bytes % 4 == 0)
+        hipLaunchKernelGGL(k_unpack_rgb<true>, dim3((w / 4 + 255) / 256, h), dim3(256), 0, c->stream,
+                           c->d_stage, row_bytes, channels, w, h, c->d_dist_u8);
+    else
+        hipLaunchKernelGGL(k_unpack_rgb<false>, dim3((w + 255) / 256, h), dim3(256), 0, c->stream,
+                           c->d_stage, row_bytes, channels, w, h, c->d_dist_u8);
+    int rc = enqueue_score(c, c->d_ref_u8, c->d_dist_u8, w, h, true);
     if (rc) return rc;
     return ssimu2_wait(c, out_score);
 }

@@ -722,4 +722,35 @@ __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decoded-frame hand-off (io.zig:654-663): libavif's RGB / RGBA rows `pitch` bytes apart ->
+// tight RGB8.  kFast: four RGBA pixels per lane, four dword loads and three dword stores
+// (needs w % 4 == 0, pitch % 4 == 0 and dword-aligned buffers); otherwise one pixel per lane
+// with byte accesses.  Pure byte movement, HBM-bound: (ch + 3) bytes per pixel.
+// ---------------------------------------------------------------------------------------------
+template <bool kFast>
+__global__ __launch_bounds__(256) void k_unpack_rgb(const uint8_t* __restrict__ src, uint32_t pitch,
+                                                    uint32_t ch, uint32_t w, uint32_t h,
+                                                    uint8_t* __restrict__ dst) {
+    const uint32_t y = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (y >= h) return;
+    if (kFast) {
+        if (i * 4u >= w) return;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(src + (size_t)y * pitch) + i * 4u;
+        const uint32_t p0 = s[0], p1 = s[1], p2 = s[2], p3 = s[3];  // LE: R | G<<8 | B<<16 | A<<24
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + ((size_t)y * w + i * 4u) * 3u);
+        d[0] = (p0 & 0x00FFFFFFu) | (p1 << 24);
+        d[1] = ((p1 >> 8) & 0x0000FFFFu) | (p2 << 16);
+        d[2] = ((p2 >> 16) & 0x000000FFu) | (p3 << 8);
+    } else {
+        if (i >= w) return;
+        const uint8_t* s = src + (size_t)y * pitch + (size_t)i * ch;
+        uint8_t* d = dst + ((size_t)y * w + i) * 3u;
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+    }
+}
+
 }  // namespace ssimu2

@@ -97,6 +97,33 @@ class Ssimu2:
             self._raise(rc)
         return out.value
 
+    def score_decoded_against_reference(self, pixels, row_bytes: int | None = None,
+                                        channels: int | None = None) -> float:
+        """Score a decoded frame in libavif's avifRGBImage layout without the CPU copy loop of
+        io.decodeAvifToRgb (io.zig:654-663): `pixels` is an (h, w, 3|4) uint8 array whose rows
+        may be padded (strides[0] >= w * channels, pixels tightly packed within a row), or a flat
+        uint8 buffer with explicit `row_bytes` / `channels`.  Alpha and padding are dropped on
+        the device."""
+        a = np.asarray(pixels)
+        if a.dtype != np.uint8:
+            raise TypeError("pixels must be uint8")
+        if a.ndim == 3:
+            if a.strides[2] != 1 or a.strides[1] != a.shape[2]:
+                raise ValueError("pixels of a row must be tightly packed")
+            if getattr(self, "_ref_shape", None) is not None and a.shape[:2] != self._ref_shape[:2]:
+                raise ValueError("frame size differs from the reference's")
+            row_bytes = a.strides[0] if row_bytes is None else row_bytes
+            channels = a.shape[2] if channels is None else channels
+        elif row_bytes is None or channels is None:
+            raise ValueError("flat buffers need row_bytes and channels")
+        out = ctypes.c_double()
+        ptr = ctypes.cast(ctypes.c_void_p(a.ctypes.data), ctypes.POINTER(ctypes.c_uint8))
+        rc = self._L.ssimu2_score_against_reference_strided(self._ctx, ptr, int(row_bytes),
+                                                            int(channels), ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
     # -- device-resident entry points (pointers are raw device addresses) -------------------
     def score_device(self, d_ref: int, d_dist: int, w: int, h: int) -> float:
         out = ctypes.c_double()

@@ -34,6 +34,7 @@ extern fn ssimu2_last_error(ctx: ?*const Ctx) [*:0]const u8;
 extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: u32, h: u32, channels: u32, out_score: *f64) c_int;
 extern fn ssimu2_set_reference(ctx: ?*Ctx, ref: [*]const u8, w: u32, h: u32) c_int;
 extern fn ssimu2_score_against_reference(ctx: ?*Ctx, dist: [*]const u8, out_score: *f64) c_int;
+extern fn ssimu2_score_against_reference_strided(ctx: ?*Ctx, pixels: [*]const u8, row_bytes: u32, channels: u32, out_score: *f64) c_int;
 
 /// HIP device the process-wide scorer context binds to (set before the first call; the
 /// batch driver gives every worker process its own device).
@@ -110,5 +111,36 @@ pub fn computeSsimu2(
         return score;
     }
     try check(ssimu2_score_rgb8(ctx, reference.ptr, distorted.ptr, width, height, channels, &score));
+    return score;
+}
+
+/// Optional deeper hand-off (needs a small edit of oavif, INTEGRATION.md section 2b): score
+/// libavif's decoded `avifRGBImage` as it is -- `pixels` = rgb.pixels, `row_bytes` = rgb.rowBytes,
+/// `src_channels` = 3 or 4 -- against `reference`, so that the per-pixel copy loop of
+/// io.decodeAvifToRgb (io.zig:654-663) and its w*h*3 allocation (io.zig:649) disappear from
+/// every pass; alpha bytes and row padding are dropped on the device.  Same score, bit for bit,
+/// as computeSsimu2 on the copied frame.
+pub fn computeSsimu2Decoded(
+    reference: []const u8,
+    pixels: [*]const u8,
+    row_bytes: u32,
+    src_channels: u32,
+    width: u32,
+    height: u32,
+) Error!f64 {
+    const need: usize = @as(usize, width) * @as(usize, height) * 3;
+    if (reference.len < need) return Error.InvalidArgument;
+    const ctx = try context();
+    const same = g_ref_ptr != null and g_ref_ptr.? == reference.ptr and
+        g_ref_len == reference.len and g_ref_w == width and g_ref_h == height;
+    if (!same or !cache_reference) {
+        try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
+        g_ref_ptr = reference.ptr;
+        g_ref_len = reference.len;
+        g_ref_w = width;
+        g_ref_h = height;
+    }
+    var score: f64 = 0;
+    try check(ssimu2_score_against_reference_strided(ctx, pixels, row_bytes, src_channels, &score));
     return score;
 }

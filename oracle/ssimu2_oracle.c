@@ -488,6 +488,24 @@ double or_score_from_averages(const double* avg /* nscales*18 */, int nscales) {
     return ssim;
 }
 
+/* /root/reference/src/io.zig:654-663 -- decodeAvifToRgb's copy of libavif's decoded rows
+   (RGB or RGBA, `row_bytes` apart) into the tight RGB8 buffer handed to the scorer.  Scalar and
+   single-threaded like the reference's loop; the checker (and CPU timing beside) the device
+   unpack behind ssimu2_score_against_reference_strided. */
+void or_copy_rgb_pixels(const uint8_t* src, size_t row_bytes, int src_channels, int w, int h,
+                        uint8_t* dst) {
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* src_row = src + (size_t)y * row_bytes;
+        for (int x = 0; x < w; ++x) {
+            const size_t si = (size_t)x * (size_t)src_channels;
+            const size_t di = ((size_t)y * (size_t)w + (size_t)x) * 3;
+            dst[di + 0] = src_row[si + 0];
+            dst[di + 1] = src_row[si + 1];
+            dst[di + 2] = src_row[si + 2];
+        }
+    }
+}
+
 /* thread count of the OpenMP build (the environment variable is read only once per process,
    and another library may have initialised the OpenMP runtime first) */
 int or_set_num_threads(int n) {

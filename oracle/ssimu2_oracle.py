@@ -58,6 +58,9 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
         lib.or_cbrtf.restype = ctypes.c_float
         lib.or_set_num_threads.argtypes = [ctypes.c_int]
         lib.or_set_num_threads.restype = ctypes.c_int
+        lib.or_copy_rgb_pixels.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, u8p]
+        lib.or_copy_rgb_pixels.restype = None
         lib.or_weights.argtypes = [f64p]
         lib.or_weights.restype = None
         _libs[omp] = lib
@@ -156,3 +159,14 @@ def cbrtf(x: float) -> float:
 def set_num_threads(n: int) -> int:
     """Thread count of the OpenMP build; returns the count in effect."""
     return int(_lib(True).or_set_num_threads(int(n)))
+
+
+def copy_rgb_pixels(pixels: np.ndarray) -> np.ndarray:
+    """io.zig:654-663 on an (h, w, 3|4) uint8 array with possibly padded rows -> tight (h, w, 3)."""
+    assert pixels.dtype == np.uint8 and pixels.ndim == 3 and pixels.strides[2] == 1
+    assert pixels.strides[1] == pixels.shape[2]
+    h, w, ch = pixels.shape
+    out = np.empty((h, w, 3), np.uint8)
+    src = ctypes.cast(ctypes.c_void_p(pixels.ctypes.data), ctypes.POINTER(ctypes.c_uint8))
+    _lib().or_copy_rgb_pixels(src, pixels.strides[0], ch, w, h, _u8(out))
+    return out

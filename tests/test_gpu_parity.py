@@ -439,3 +439,61 @@ def test_any_segment_length_gives_the_same_score(hip_lib, scorer, seg, tail, mon
     with oavif_amd.Ssimu2(0) as s:
         got = s.compute_ssimu2(ref, dist)
     assert abs(got - expect) < 1e-7
+
+
+def _decoded_like(dist, channels, pad, seed):
+    """`dist` laid out like libavif's avifRGBImage: `channels` bytes per pixel (alpha random),
+    rows `pad` bytes longer than their pixels, padding filled with noise."""
+    h, w, _ = dist.shape
+    rng = np.random.default_rng(seed)
+    pitch = w * channels + pad
+    buf = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    view = np.lib.stride_tricks.as_strided(buf, (h, w, channels), (pitch, channels, 1))
+    view[..., :3] = dist
+    return buf, view
+
+
+@pytest.mark.parametrize("w,h,channels,pad", [
+    (640, 360, 4, 0), (640, 360, 4, 64), (641, 359, 4, 0), (642, 100, 4, 2), (643, 77, 4, 3),
+    (640, 360, 3, 0), (640, 360, 3, 32), (333, 217, 3, 1), (8, 8, 4, 0), (9, 9, 4, 5),
+    (3840, 2160, 4, 0), (1920, 1080, 4, 0)])
+def test_decoded_frame_handoff_matches_cpu_copy(scorer, oracle, w, h, channels, pad):
+    """ssimu2_score_against_reference_strided on libavif's RGB(A) rows == the reference's CPU
+    copy loop (io.zig:654-663, restated by the oracle) followed by the plain score."""
+    ref = synth.make_ref(w, h, 71)
+    dist = synth.distort(ref, "blockq", 1)
+    buf, view = _decoded_like(dist, channels, pad, seed=w + h)
+    tight = oracle.copy_rgb_pixels(view)
+    assert np.array_equal(tight, dist)
+    scorer.set_reference(ref)
+    expect = scorer.score_against_reference(tight)
+    assert scorer.score_decoded_against_reference(view) == expect
+    # flat-buffer form, as a C caller passes rgb.pixels / rgb.rowBytes
+    assert scorer.score_decoded_against_reference(buf.reshape(-1), row_bytes=buf.shape[1],
+                                                  channels=channels) == expect
+    # repeated and interleaved with the tight path: the staging buffer is private
+    assert scorer.score_against_reference(tight) == expect
+    assert scorer.score_decoded_against_reference(view) == expect
+
+
+def test_decoded_frame_handoff_errors(scorer):
+    from oavif_amd import Ssimu2Error, _lib
+    ref = synth.make_ref(64, 48, 3)
+    rgba = np.zeros((48, 64, 4), np.uint8)
+    with oavif_amd_scorer() as s:
+        with pytest.raises(Ssimu2Error) as ei:       # no reference yet
+            s.score_decoded_against_reference(rgba)
+        assert ei.value.code == _lib.ERR_NO_REFERENCE
+        s.set_reference(ref)
+        with pytest.raises(Ssimu2Error) as ei:       # grey+alpha is not a decoder output
+            s.score_decoded_against_reference(np.zeros(48 * 64 * 2, np.uint8), row_bytes=128, channels=2)
+        assert ei.value.code == _lib.ERR_UNSUPPORTED
+        with pytest.raises(Ssimu2Error) as ei:       # rows shorter than their pixels
+            s.score_decoded_against_reference(rgba.reshape(-1), row_bytes=64 * 4 - 1, channels=4)
+        assert ei.value.code == _lib.ERR_INVALID_ARG
+        assert s.score_decoded_against_reference(np.concatenate([ref, rgba[..., 3:]], axis=2)) == 100.0
+
+
+def oavif_amd_scorer():
+    import oavif_amd
+    return oavif_amd.Ssimu2(0)

@@ -243,3 +243,14 @@ def test_fp32_fir_is_closer_to_the_exact_operator_than_the_fp32_recursion(oracle
     assert max(d_fir) < 5e-3, d_fir
     assert np.mean(d_iir) > 8 * np.mean(d_fir), (d_fir, d_iir)
     assert max(d_iir) > 20 * max(d_fir), (d_fir, d_iir)
+
+
+def test_copy_rgb_pixels_drops_alpha_and_padding(oracle):
+    """io.zig:654-663 restated: the tight RGB copy equals plain slicing for RGB / RGBA rows with
+    and without padding."""
+    rng = np.random.default_rng(5)
+    for ch, w, h, pad in ((4, 11, 7, 6), (3, 16, 5, 0), (3, 9, 4, 5), (4, 8, 3, 0)):
+        pitch = w * ch + pad
+        buf = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+        view = np.lib.stride_tricks.as_strided(buf, (h, w, ch), (pitch, ch, 1))
+        assert np.array_equal(oracle.copy_rgb_pixels(view), view[..., :3])
