@@ -55,6 +55,20 @@ int main(int argc, char** argv) {
     if ((rc = ssimu2_set_reference(ctx, ref, w, h))) goto fail;
     if ((rc = ssimu2_score_against_reference(ctx, dist, &cached))) goto fail;
     if (ssimu2_score_rgb8(ctx, ref, dist, w, h, 4, &pair) != SSIMU2_ERR_UNSUPPORTED) { rc = 99; goto fail; }
+    {   /* the frame as libavif hands it over: RGBA, rows 8 bytes longer than their pixels */
+        const uint32_t pitch = w * 4 + 8;
+        uint8_t* rgba = (uint8_t*)malloc((size_t)pitch * h);
+        double strided = 0;
+        if (!rgba) return 2;
+        for (size_t i = 0; i < (size_t)pitch * h; ++i) rgba[i] = (uint8_t)rnd();
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x)
+                memcpy(rgba + (size_t)y * pitch + (size_t)x * 4, dist + ((size_t)y * w + x) * 3, 3);
+        rc = ssimu2_score_against_reference_strided(ctx, rgba, pitch, 4, &strided);
+        free(rgba);
+        if (rc) goto fail;
+        if (strided != cached) { rc = 98; goto fail; }
+    }
 
     oavif_tq_options o;
     oavif_tq_default_options(&o);
