@@ -497,3 +497,49 @@ def test_decoded_frame_handoff_errors(scorer):
 def oavif_amd_scorer():
     import oavif_amd
     return oavif_amd.Ssimu2(0)
+
+
+def _flip(a):
+    return np.ascontiguousarray(a[::-1, ::-1])
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1088), (640, 352), (1000, 700)])
+def test_flip_invariance(scorer, oracle, w, h):
+    """Mirroring both frames leaves the metric unchanged: the blur taps are symmetric and their
+    pair sums commute, the maps are pointwise; only the fp64 summation order moves.  For
+    dimensions that are multiples of 32 every scale is mirrored exactly; ragged ones (1000x700)
+    clamp the odd edge at the other end, so only the oracle comparison applies there."""
+    ref = synth.make_ref(w, h, 83)
+    dist = synth.distort(ref, "blockq", 2)
+    dist[-40:, -40:] = 255 - dist[-40:, -40:]          # something only the far corner holds
+    a = scorer.compute_ssimu2(ref, dist)
+    b = scorer.compute_ssimu2(_flip(ref), _flip(dist))
+    if w % 32 == 0 and h % 32 == 0:
+        assert abs(a - b) < 1e-9
+    assert abs(b - oracle.compute_ssimu2(_flip(ref), _flip(dist), oracle.BLUR_FIR)) <= TOL_SCORE
+
+
+def test_maximum_size_far_corner_is_addressed_correctly(scorer):
+    """23168 x 23168 (0.54 Gpx, 1.6 GB per frame; the ABI's limit is 2^31/3 px): every index
+    the kernels form must survive sizes where 32-bit element offsets overflow.  No oracle run
+    at this size; the size-independent property is flip invariance with a distortion that only
+    the far corner holds -- a far-end row or plane offset that wrapped would score the mirrored
+    pair differently -- plus identical -> 100 and the patch being seen at all."""
+    n, t = 23168, 2896                                  # 8 x 8 tiles, t % 32 == 0
+    base = synth.make_ref(t, t, 97)
+    ref = np.tile(base, (8, 8, 1))
+    dist = np.tile(synth.distort(base, "blockq", 1), (8, 8, 1))
+    assert ref.shape == (n, n, 3)
+    without = scorer.compute_ssimu2(ref, dist)
+    dist[-512:, -512:] = 255 - dist[-512:, -512:]
+    s = scorer.compute_ssimu2(ref, dist)
+    _, ns = scorer.last_averages()
+    assert ns == 6
+    assert s < without < 100.0                          # the far corner is read
+    rf, df = _flip(ref), _flip(dist)
+    del dist
+    assert abs(scorer.compute_ssimu2(rf, df) - s) < 1e-9
+    scorer.set_reference(rf)
+    assert scorer.score_against_reference(df) == scorer.compute_ssimu2(rf, df)
+    del df
+    assert scorer.compute_ssimu2(ref, ref) == 100.0
