@@ -499,46 +499,52 @@ def oavif_amd_scorer():
     return oavif_amd.Ssimu2(0)
 
 
+FLIP_TOL = 2e-3   # points; rounding-order effect of mirroring, see test_flip_invariance
+
+
 def _flip(a):
     return np.ascontiguousarray(a[::-1, ::-1])
 
 
 @pytest.mark.parametrize("w,h", [(1920, 1088), (640, 352), (1000, 700)])
 def test_flip_invariance(scorer, oracle, w, h):
-    """Mirroring both frames leaves the metric unchanged: the blur taps are symmetric and their
-    pair sums commute, the maps are pointwise; only the fp64 summation order moves.  For
-    dimensions that are multiples of 32 every scale is mirrored exactly; ragged ones (1000x700)
-    clamp the odd edge at the other end, so only the oracle comparison applies there."""
+    """Mirroring both frames leaves the metric unchanged in exact arithmetic (symmetric taps,
+    pointwise maps) when the dimensions are multiples of 32, so that every scale is mirrored too.
+    In fp32 it moves by rounding order only -- the 2x2 box sum and the fused pair products
+    fma(a-*b-, a+*b+) of the arithmetic contract are not mirror-symmetric in rounding -- which is
+    ~1e-4 of a point here (FLIP_TOL); the mirrored pair still matches the oracle to TOL_SCORE.
+    Ragged sizes (1000x700) clamp the odd edge at the other end: oracle comparison only."""
     ref = synth.make_ref(w, h, 83)
     dist = synth.distort(ref, "blockq", 2)
     dist[-40:, -40:] = 255 - dist[-40:, -40:]          # something only the far corner holds
     a = scorer.compute_ssimu2(ref, dist)
     b = scorer.compute_ssimu2(_flip(ref), _flip(dist))
     if w % 32 == 0 and h % 32 == 0:
-        assert abs(a - b) < 1e-9
+        assert abs(a - b) < FLIP_TOL
     assert abs(b - oracle.compute_ssimu2(_flip(ref), _flip(dist), oracle.BLUR_FIR)) <= TOL_SCORE
 
 
 def test_maximum_size_far_corner_is_addressed_correctly(scorer):
     """23168 x 23168 (0.54 Gpx, 1.6 GB per frame; the ABI's limit is 2^31/3 px): every index
     the kernels form must survive sizes where 32-bit element offsets overflow.  No oracle run
-    at this size; the size-independent property is flip invariance with a distortion that only
-    the far corner holds -- a far-end row or plane offset that wrapped would score the mirrored
-    pair differently -- plus identical -> 100 and the patch being seen at all."""
+    at this size; the size-independent property is flip invariance (to FLIP_TOL) with a strong
+    distortion that only the far corner tile holds -- a far-end row or plane offset that wrapped
+    would score the mirrored pair differently by about the patch's whole effect -- plus
+    identical -> 100 and the patch being seen at all."""
     n, t = 23168, 2896                                  # 8 x 8 tiles, t % 32 == 0
     base = synth.make_ref(t, t, 97)
     ref = np.tile(base, (8, 8, 1))
     dist = np.tile(synth.distort(base, "blockq", 1), (8, 8, 1))
     assert ref.shape == (n, n, 3)
     without = scorer.compute_ssimu2(ref, dist)
-    dist[-512:, -512:] = 255 - dist[-512:, -512:]
+    dist[-t:, -t:] = 255 - dist[-t:, -t:]
     s = scorer.compute_ssimu2(ref, dist)
     _, ns = scorer.last_averages()
     assert ns == 6
-    assert s < without < 100.0                          # the far corner is read
+    assert s + 100 * FLIP_TOL < without < 100.0         # the far corner is read, and matters
     rf, df = _flip(ref), _flip(dist)
     del dist
-    assert abs(scorer.compute_ssimu2(rf, df) - s) < 1e-9
+    assert abs(scorer.compute_ssimu2(rf, df) - s) < FLIP_TOL
     scorer.set_reference(rf)
     assert scorer.score_against_reference(df) == scorer.compute_ssimu2(rf, df)
     del df
