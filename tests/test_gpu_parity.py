@@ -525,16 +525,17 @@ def test_flip_invariance(scorer, oracle, w, h):
 
 
 def test_maximum_size_far_corner_is_addressed_correctly(scorer):
-    """23168 x 23168 (0.54 Gpx, 1.6 GB per frame; the ABI's limit is 2^31/3 px): every index
+    """26752 x 26752 (0.716 Gpx, 2.147 GB per frame: 475 KB under the ABI's limit of 2^31/3 px,
+    the frame's bytes just fit a signed 32-bit offset and its fp32 planes do not): every index
     the kernels form must survive sizes where 32-bit element offsets overflow.  No oracle run
     at this size; the size-independent property is flip invariance (to FLIP_TOL) with a strong
     distortion that only the far corner tile holds -- a far-end row or plane offset that wrapped
     would score the mirrored pair differently by about the patch's whole effect -- plus
     identical -> 100 and the patch being seen at all."""
-    n, t = 23168, 2896                                  # 8 x 8 tiles, t % 32 == 0
+    n, t, reps = 26752, 2432, 11                        # 11 x 11 tiles, t % 32 == 0
     base = synth.make_ref(t, t, 97)
-    ref = np.tile(base, (8, 8, 1))
-    dist = np.tile(synth.distort(base, "blockq", 1), (8, 8, 1))
+    ref = np.tile(base, (reps, reps, 1))
+    dist = np.tile(synth.distort(base, "blockq", 1), (reps, reps, 1))
     assert ref.shape == (n, n, 3)
     without = scorer.compute_ssimu2(ref, dist)
     dist[-t:, -t:] = 255 - dist[-t:, -t:]
