@@ -85,6 +85,47 @@ int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uin
                         uint32_t w, uint32_t h, oavif_tq_codec_fn codec, void* user,
                         oavif_tq_result* out, size_t* out_last_avif_size);
 
+/* ---- speculative probe fan-out (one search, several probes in flight) -------------------
+ *
+ * The reference runs the passes of a search strictly one after another: the next quantizer
+ * depends on every score so far (tq.zig:135-139).  On a host with idle cores and a scorer
+ * that takes 0.2 ms, the probes that the search is LIKELY to ask for next can be encoded,
+ * decoded and scored at the same time as the one it asked for (one scorer context / HIP
+ * stream each), and the search replayed over the cached scores.
+ *
+ * oavif_tq_find_target_quality_speculative runs exactly the control flow of
+ * oavif_tq_find_target_quality.  When it needs the score of a quantizer nobody has probed
+ * yet, it issues one WAVE through `batch`: that quantizer first, plus up to max_fanout-1
+ * candidates for the following pass -- found by running the same search code forward under
+ * hypothetical scores for the missing quantizer (an estimate from the probes known so far,
+ * or from the model of tq.zig:40-43, shifted by tolerance+0.5, +1.5, ... points either way).
+ * Wrong guesses cost CPU time only: the result -- q, score, num_pass, buf_q, history -- is
+ * that of the sequential search as long as score(q) is a function of q (the HIP scorer is
+ * deterministic).  num_pass keeps the reference's meaning (passes the sequential search
+ * would have run); the extra work is reported in oavif_tq_spec_stats.
+ */
+#define OAVIF_TQ_MAX_FANOUT 16
+
+/* Probe `n` distinct quantizers (encode -> decode -> score each; they may run concurrently)
+   and store their scores in out_scores[0..n).  qs[0] is the one the search is waiting for.
+   Return 0 on success; any other value aborts the search and is returned by it. */
+typedef int (*oavif_tq_batch_probe_fn)(void* user, const uint32_t* qs, uint32_t n, double* out_scores);
+
+typedef struct {
+    uint32_t max_fanout; /* probes per wave, 1..OAVIF_TQ_MAX_FANOUT; 1 = the sequential search */
+} oavif_tq_spec_options;
+
+typedef struct {
+    uint32_t waves;         /* calls of `batch` (the latency of the search, in passes)          */
+    uint32_t probes_issued; /* quantizers encoded + scored in total (>= result.num_pass)        */
+    uint32_t cache_hits;    /* passes of the search answered by an earlier wave                 */
+} oavif_tq_spec_stats;
+
+int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
+                                             const oavif_tq_spec_options* so,
+                                             oavif_tq_batch_probe_fn batch, void* user,
+                                             oavif_tq_result* out, oavif_tq_spec_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "ssimu2_version",
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
+    "oavif_tq_find_target_quality_speculative",
 )
 
 
@@ -53,6 +54,18 @@ class TQResult(ctypes.Structure):
                 ("history_len", ctypes.c_uint32), ("history", TQPass * TQ_MAX_PASS)]
 
 
+class TQSpecOptions(ctypes.Structure):
+    _fields_ = [("max_fanout", ctypes.c_uint32)]
+
+
+class TQSpecStats(ctypes.Structure):
+    _fields_ = [("waves", ctypes.c_uint32), ("probes_issued", ctypes.c_uint32),
+                ("cache_hits", ctypes.c_uint32)]
+
+
+TQ_MAX_FANOUT = 16
+BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                  ctypes.c_uint32, ctypes.POINTER(ctypes.c_double))
 PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
                             ctypes.POINTER(ctypes.c_double))
 CODEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
@@ -125,6 +138,10 @@ def lib() -> ctypes.CDLL:
     L.oavif_tq_find_target_quality.argtypes = [ctypes.POINTER(TQOptions), PROBE_FN, vp,
                                                ctypes.POINTER(TQResult)]
     L.oavif_tq_find_target_quality.restype = ci
+    L.oavif_tq_find_target_quality_speculative.argtypes = [
+        ctypes.POINTER(TQOptions), ctypes.POINTER(TQSpecOptions), BATCH_PROBE_FN, vp,
+        ctypes.POINTER(TQResult), ctypes.POINTER(TQSpecStats)]
+    L.oavif_tq_find_target_quality_speculative.restype = ci
     L.oavif_tq_search_hip.argtypes = [ctypes.POINTER(TQOptions), vp, u8p, u32, u32, CODEC_FN, vp,
                                       ctypes.POINTER(TQResult), ctypes.POINTER(ctypes.c_size_t)]
     L.oavif_tq_search_hip.restype = ci

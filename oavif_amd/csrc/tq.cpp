@@ -190,6 +190,108 @@ int oavif_tq_find_target_quality(const oavif_tq_options* o, oavif_tq_probe_fn pr
 }
 
 namespace {
+
+// ---- speculative probe fan-out -------------------------------------------------------------
+struct Spec {
+    const oavif_tq_options* o;
+    uint32_t fanout;
+    oavif_tq_batch_probe_fn batch;
+    void* user;
+    bool known[101];
+    double score[101];
+    oavif_tq_spec_stats stats;
+};
+
+constexpr int kSimStop = 0x7157;  // private return code: the simulated search asked for a new q
+
+struct Sim {
+    const Spec* s;
+    uint32_t q_miss;
+    double hyp;
+    int32_t next;
+};
+
+int sim_probe(void* p, uint32_t q, double* out_score) {
+    Sim* m = (Sim*)p;
+    if (q <= 100 && m->s->known[q]) {
+        *out_score = m->s->score[q];
+        return 0;
+    }
+    if (q == m->q_miss) {
+        *out_score = m->hyp;
+        return 0;
+    }
+    m->next = (int32_t)q;
+    return kSimStop;
+}
+
+// Score the search may see at `q`: between two probed quantizers, the line through them;
+// otherwise the model behind the first guess (tq.zig:41 inverted: score = ln(q / 6.83) / 0.0282)
+// shifted to pass through the nearest probe.
+double estimate_score(const Spec& s, uint32_t q) {
+    int below = -1, above = -1;
+    for (int k = (int)q - 1; k >= 0 && below < 0; --k)
+        if (s.known[k]) below = k;
+    for (int k = (int)q + 1; k <= 100 && above < 0; ++k)
+        if (s.known[k]) above = k;
+    if (below >= 0 && above >= 0) {
+        const double t = ((double)q - below) / ((double)above - below);
+        return s.score[below] + (s.score[above] - s.score[below]) * t;
+    }
+    auto model = [](double qq) { return std::log(std::fmax(qq, 1.0) / 6.83) / 0.0282; };
+    const int near = below >= 0 ? below : above;
+    if (near < 0) return model((double)q);
+    return model((double)q) + (s.score[near] - model((double)near));
+}
+
+// Candidates for the pass after `q_miss`: what the search would ask for next if q_miss scored
+// est +- (tolerance + 0.5 + k), k = 0, 1, 2, ...  (inside the tolerance the search ends).
+void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n) {
+    const double est = estimate_score(s, q_miss);
+    for (int k = 0; k < 24 && *n < s.fanout; ++k) {
+        for (int sign = +1; sign >= -1 && *n < s.fanout; sign -= 2) {
+            Sim m{&s, q_miss, est + sign * (s.o->tolerance + 0.5 + k), -1};
+            // hypothetical scores relative to the TARGET as well: the pass-0 bounds depend on
+            // |score - target| only, and the estimate may be far off for unusual content
+            for (int rel = 0; rel < 2 && *n < s.fanout; ++rel) {
+                if (rel == 1) m.hyp = s.o->score_tgt + sign * (s.o->tolerance + 0.5 + k);
+                m.next = -1;
+                oavif_tq_result tmp;
+                const int rc = oavif_tq_find_target_quality(s.o, sim_probe, &m, &tmp);
+                if (rc != kSimStop || m.next < 0 || m.next > 100) continue;
+                bool dup = false;
+                for (uint32_t i = 0; i < *n; ++i) dup |= wave[i] == (uint32_t)m.next;
+                if (!dup) wave[(*n)++] = (uint32_t)m.next;
+            }
+        }
+    }
+}
+
+int replay_probe(void* p, uint32_t q, double* out_score) {
+    Spec* s = (Spec*)p;
+    if (q > 100) return SSIMU2_ERR_INVALID_ARG;  // unreachable: every proposal is clamped to 0..100
+    if (s->known[q]) {
+        s->stats.cache_hits += 1;
+        *out_score = s->score[q];
+        return 0;
+    }
+    uint32_t wave[OAVIF_TQ_MAX_FANOUT];
+    double sc[OAVIF_TQ_MAX_FANOUT];
+    uint32_t n = 0;
+    wave[n++] = q;
+    if (s->fanout > 1) add_candidates(*s, q, wave, &n);
+    const int rc = s->batch(s->user, wave, n, sc);
+    if (rc != 0) return rc;
+    s->stats.waves += 1;
+    s->stats.probes_issued += n;
+    for (uint32_t i = 0; i < n; ++i) {
+        s->known[wave[i]] = true;
+        s->score[wave[i]] = sc[i];
+    }
+    *out_score = s->score[q];
+    return 0;
+}
+
 struct HipPass {
     ssimu2_ctx* scorer;
     oavif_tq_codec_fn codec;
@@ -207,6 +309,22 @@ int hip_probe(void* p, uint32_t q, double* out_score) {
     return ssimu2_score_against_reference(s->scorer, s->decoded, out_score);  // tq.zig:37
 }
 }  // namespace
+
+int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
+                                             const oavif_tq_spec_options* so,
+                                             oavif_tq_batch_probe_fn batch, void* user,
+                                             oavif_tq_result* out, oavif_tq_spec_stats* stats) {
+    if (!o || !so || !batch || !out) return SSIMU2_ERR_INVALID_ARG;
+    if (so->max_fanout < 1 || so->max_fanout > OAVIF_TQ_MAX_FANOUT) return SSIMU2_ERR_INVALID_ARG;
+    Spec s{};
+    s.o = o;
+    s.fanout = so->max_fanout;
+    s.batch = batch;
+    s.user = user;
+    const int rc = oavif_tq_find_target_quality(o, replay_probe, &s, out);
+    if (stats) *stats = s.stats;
+    return rc;
+}
 
 int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uint8_t* ref_rgb,
                         uint32_t w, uint32_t h, oavif_tq_codec_fn codec, void* user,

@@ -73,6 +73,86 @@ def find_target_quality(probe: Callable[[int], float], score_tgt: float = 80.0,
     return _result(res)
 
 
+@dataclass
+class SpecStats:
+    waves: int = 0           # batches of concurrent probes = the latency of the search in passes
+    probes_issued: int = 0   # quantizers encoded + scored in total
+    cache_hits: int = 0      # passes answered by an earlier wave
+
+
+def find_target_quality_speculative(batch_probe: Callable[[List[int]], List[float]],
+                                    score_tgt: float = 80.0, tolerance: float = 2.0,
+                                    max_pass: int = 6, max_fanout: int = 4):
+    """`findTargetQuality` with several probes in flight (include/oavif_tq.h, "speculative probe
+    fan-out").  batch_probe(qs) -> scores probes the quantizers of one wave, qs[0] being the one
+    the search waits for.  -> (TQResult, SpecStats); the TQResult equals the sequential one."""
+    L = _lib.lib()
+    err: list = []
+
+    def _cb(_user, qs, n, out):
+        try:
+            want = [int(qs[i]) for i in range(n)]
+            got = list(batch_probe(want))
+            if len(got) != n:
+                raise ValueError(f"batch_probe returned {len(got)} scores for {n} quantizers")
+            for i in range(n):
+                out[i] = float(got[i])
+            return 0
+        except Exception as e:
+            err.append(e)
+            return -100
+
+    cb = _lib.BATCH_PROBE_FN(_cb)
+    res = _lib.TQResult()
+    stats = _lib.TQSpecStats()
+    opts = _options(score_tgt, tolerance, max_pass)
+    so = _lib.TQSpecOptions(int(max_fanout))
+    rc = L.oavif_tq_find_target_quality_speculative(ctypes.byref(opts), ctypes.byref(so), cb, None,
+                                                    ctypes.byref(res), ctypes.byref(stats))
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise Ssimu2Error(rc, "oavif_tq_find_target_quality_speculative failed")
+    return _result(res), SpecStats(int(stats.waves), int(stats.probes_issued), int(stats.cache_hits))
+
+
+def search_speculative_hip(scorers, ref_rgb: np.ndarray,
+                           codec: Callable[[int], Tuple[np.ndarray, int]], score_tgt: float = 80.0,
+                           tolerance: float = 2.0, max_pass: int = 6, max_fanout: int | None = None):
+    """One search with its probes fanned over `scorers` (one context = one HIP stream each, same
+    device) and as many host threads: every probe of a wave runs codec(q) -- the CPU encode +
+    decode -- and scores its frame on its own context, so the GPU work of one probe overlaps the
+    CPU work of the others (BASELINE configs[2]).  -> (TQResult, SpecStats, {q: avif size})."""
+    from concurrent.futures import ThreadPoolExecutor
+    scorers = list(scorers)
+    if not scorers:
+        raise ValueError("need at least one scorer context")
+    fan = min(len(scorers), _lib.TQ_MAX_FANOUT) if max_fanout is None else int(max_fanout)
+    if fan > len(scorers):
+        raise ValueError("max_fanout exceeds the number of scorer contexts")
+    ref = np.ascontiguousarray(ref_rgb, dtype=np.uint8)
+    for s in scorers[:fan]:
+        s.set_reference(ref)
+    sizes: dict = {}
+
+    def one(args):
+        slot, q = args
+        dec, size = codec(q)
+        dec = np.ascontiguousarray(dec, dtype=np.uint8)
+        if dec.shape != ref.shape:
+            raise ValueError(f"codec returned {dec.shape}, expected {ref.shape}")
+        sizes[q] = int(size)
+        return scorers[slot].score_against_reference(dec)
+
+    with ThreadPoolExecutor(max_workers=fan) as pool:
+        def batch(qs):
+            return list(pool.map(one, list(enumerate(qs))))
+
+        res, stats = find_target_quality_speculative(batch, score_tgt, tolerance, max_pass, fan)
+    res.last_avif_size = sizes.get(res.buf_q, 0)
+    return res, stats, sizes
+
+
 def search_hip(scorer: Ssimu2, ref_rgb: np.ndarray,
                codec: Callable[[int], Tuple[np.ndarray, int]], score_tgt: float = 80.0,
                tolerance: float = 2.0, max_pass: int = 6) -> TQResult:

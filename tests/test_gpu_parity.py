@@ -157,6 +157,16 @@ def test_error_codes(scorer):
     with pytest.raises(Ssimu2Error) as ei:
         Ssimu2(99)
     assert ei.value.code == _lib.ERR_NO_DEVICE
+    # dimensions are validated before any byte is touched: zero sizes and frames over the
+    # 2^31/3-pixel limit are refused (the buffer behind the pointer is never read)
+    import ctypes
+    L = _lib.lib()
+    out = ctypes.c_double()
+    p8 = ref.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    for w, h in ((0, 32), (32, 0), (26753, 26757), (65536, 65536), (2**32 - 1, 2**32 - 1)):
+        assert L.ssimu2_score_rgb8(scorer._ctx, p8, p8, w, h, 3, ctypes.byref(out)) == _lib.ERR_INVALID_ARG
+        assert L.ssimu2_set_reference(scorer._ctx, p8, w, h) == _lib.ERR_INVALID_ARG
+    assert scorer.compute_ssimu2(ref, ref) == 100.0    # the context is still usable
 
 
 def test_published_recursion_gap_reported(scorer, oracle, golden):
@@ -550,3 +560,56 @@ def test_maximum_size_far_corner_is_addressed_correctly(scorer):
     assert scorer.score_against_reference(df) == scorer.compute_ssimu2(rf, df)
     del df
     assert scorer.compute_ssimu2(ref, ref) == 100.0
+
+
+# ---- probes of one search fanned over contexts / HIP streams (BASELINE configs[2]) --
+
+def _pseudo_codec(ref):
+    """Deterministic stand-in for encode(q) -> decode: coarser block quantisation for lower q."""
+    def codec(q):
+        step = 1 + (100 - q) // 3
+        dec = (ref.astype(np.int32) // step) * step + step // 2
+        return np.clip(dec, 0, 255).astype(np.uint8), 1000 + 10 * q
+    return codec
+
+
+@pytest.mark.parametrize("w,h,tgt,fan", [(1920, 1080, 80.0, 4), (1920, 1080, 65.0, 6),
+                                         (7680, 4320, 80.0, 4)])
+def test_speculative_search_over_streams_equals_sequential(hip_lib, scorer, w, h, tgt, fan):
+    """The probes of one search run concurrently, each on its own scorer context (HIP stream)
+    and host thread; the result must be the sequential search's, pass for pass.  7680x4320 is
+    BASELINE configs[2]'s frame size (its 10-bit switch changes the CPU encode only)."""
+    import oavif_amd
+    from oavif_amd import tq
+    ref = synth.make_ref(w, h, 77)
+    codec = _pseudo_codec(ref)
+    seq = tq.search_hip(scorer, ref, codec, score_tgt=tgt)
+    ctxs = [oavif_amd.Ssimu2(0) for _ in range(fan)]
+    try:
+        res, stats, sizes = tq.search_speculative_hip(ctxs, ref, codec, score_tgt=tgt)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert (res.q, res.score, res.num_pass, res.buf_q) == (seq.q, seq.score, seq.num_pass, seq.buf_q)
+    assert res.history == seq.history
+    assert res.last_avif_size == seq.last_avif_size == 1000 + 10 * seq.buf_q
+    assert stats.waves + stats.cache_hits == seq.num_pass and stats.waves <= seq.num_pass
+    assert stats.probes_issued == len(sizes) <= stats.waves * fan
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+@pytest.mark.parametrize("seed,tgt", [(0, 80.0), (1, 70.0)])
+def test_speculative_search_with_real_avif_codec(hip_lib, scorer, seed, tgt):
+    import oavif_amd
+    from oavif_amd import tq
+    ref = synth.make_ref(640, 480, 300 + seed)
+    codec = lambda q: synth.avif_roundtrip(ref, q, speed=9)
+    seq = tq.search_hip(scorer, ref, codec, score_tgt=tgt)
+    ctxs = [oavif_amd.Ssimu2(0) for _ in range(8)]
+    try:
+        res, stats, _ = tq.search_speculative_hip(ctxs, ref, codec, score_tgt=tgt)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert (res.q, res.score, res.num_pass, res.history) == (seq.q, seq.score, seq.num_pass, seq.history)
+    assert stats.waves <= seq.num_pass

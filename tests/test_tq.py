@@ -187,3 +187,88 @@ def test_cpp_matches_restatement_on_random_curves(tq, fn, tgt, tol, max_pass):
        tgt=st.floats(30.0, 100.0), max_pass=st.integers(1, 12))
 def test_cpp_matches_restatement_on_arbitrary_tables(tq, scores, tgt, max_pass):
     run_both(tq, lambda q: scores[q], score_tgt=tgt, tolerance=1.0, max_pass=max_pass)
+
+
+# ---- speculative probe fan-out (include/oavif_tq.h): same result as the sequential search -----
+def run_speculative(tq, fn, fanout, **kw):
+    """The speculative search against the restatement of tq.zig, plus the wave invariants."""
+    waves = []
+
+    def batch(qs):
+        waves.append(list(qs))
+        return [fn(q) for q in qs]
+
+    res, stats = tq.find_target_quality_speculative(batch, max_fanout=fanout, **kw)
+    ref = tq_oracle.find_target_quality(fn, **kw)
+    assert (res.q, res.num_pass, res.buf_q) == (ref.q, ref.num_pass, ref.buf_q)
+    assert res.score == ref.score and res.history == ref.history
+    issued = [q for w in waves for q in w]
+    assert len(issued) == len(set(issued)), "a quantizer was probed twice"
+    assert all(0 <= q <= 100 for q in issued)
+    assert all(1 <= len(w) <= fanout for w in waves)
+    # every wave starts with the quantizer the search is waiting for, in the search's order
+    demanded = [w[0] for w in waves]
+    order = [q for q, _ in ref.history]
+    assert demanded == [q for q in order if q in demanded]
+    assert stats.waves == len(waves) and stats.probes_issued == len(issued)
+    assert stats.waves + stats.cache_hits == ref.num_pass
+    if fanout == 1:
+        assert demanded == order
+    return res, stats
+
+
+@pytest.mark.parametrize("fanout", [1, 2, 4, 16])
+def test_speculative_hand_trace(tq, fanout):
+    table = {65: 84.3, 55: 77.1, 59: 79.2}        # SURVEY 8a hand trace
+    res, stats = run_speculative(tq, lambda q: table.get(q, 60.0 + q / 5.0), fanout)
+    assert (res.q, res.num_pass) == (59, 3)
+    if fanout == 16:
+        assert stats.waves < 3                       # 55 = 65 - 2*ceil(4.3) is a pass-0 candidate
+
+
+@settings(max_examples=int(__import__('os').environ.get('TQ_EXAMPLES', 300)), deadline=None,
+          derandomize='TQ_EXAMPLES' not in __import__('os').environ)
+@given(fn=score_curves(), tgt=st.floats(30.0, 100.0), tol=st.floats(1.0, 10.0),
+       max_pass=st.integers(1, 12), fanout=st.integers(1, 16))
+def test_speculative_matches_sequential_on_random_curves(tq, fn, tgt, tol, max_pass, fanout):
+    run_speculative(tq, fn, fanout, score_tgt=tgt, tolerance=tol, max_pass=max_pass)
+
+
+@settings(max_examples=int(__import__('os').environ.get('TQ_EXAMPLES', 200)), deadline=None,
+          derandomize='TQ_EXAMPLES' not in __import__('os').environ)
+@given(scores=st.lists(st.floats(-40.0, 100.0), min_size=101, max_size=101),
+       tgt=st.floats(30.0, 100.0), max_pass=st.integers(1, 12), fanout=st.integers(1, 16))
+def test_speculative_matches_sequential_on_arbitrary_tables(tq, scores, tgt, max_pass, fanout):
+    run_speculative(tq, lambda q: scores[q], fanout, score_tgt=tgt, tolerance=1.0, max_pass=max_pass)
+
+
+def test_speculative_errors(tq):
+    from oavif_amd import Ssimu2Error
+
+    class Boom(Exception):
+        pass
+
+    def bad(qs):
+        raise Boom()
+    with pytest.raises(Boom):
+        tq.find_target_quality_speculative(bad)
+    with pytest.raises(ValueError):
+        tq.find_target_quality_speculative(lambda qs: [50.0])   # one score for a wave of four
+    for fan in (0, 17):
+        with pytest.raises(Ssimu2Error):
+            tq.find_target_quality_speculative(lambda qs: [50.0] * len(qs), max_fanout=fan)
+
+
+def test_speculation_saves_waves_on_typical_curves(tq):
+    """Not a correctness property: on smooth rate-quality curves around the model of tq.zig:41
+    a fan-out of 8 answers a good share of the passes from an earlier wave."""
+    import random
+    passes = waves = 0
+    for seed in range(100):
+        r = random.Random(seed)
+        off, noise = r.uniform(-8, 8), [r.uniform(-0.5, 0.5) for _ in range(101)]
+        fn = lambda q: math.log(max(q, 1) / 6.83) / 0.0282 + off + noise[q]
+        res, stats = run_speculative(tq, fn, 8)
+        passes += res.num_pass
+        waves += stats.waves
+    assert waves < 0.85 * passes
