@@ -315,6 +315,36 @@ def main() -> int:
             except Exception as e:  # the codec is not part of the measured path
                 out["search_pass_end_to_end_4k"] = {"error": str(e)}
 
+        # ---- one whole 4K search, sequential vs probes fanned over contexts/streams + host
+        # threads: same result, fewer waves of encode latency ----------------
+        if world == 1 and synth.have_avif() and not args.no_cpu_baseline:
+            try:
+                from oavif_amd import tq as _tqs
+                fan = max(1, min(8, (usable_cores() or 2) // 2))
+                codec4k = lambda q: synth.avif_roundtrip(ref, q, speed=9)
+                t0 = time.perf_counter()
+                seq = _tqs.search_hip(scorer, ref, codec4k, score_tgt=80.0)
+                t1 = time.perf_counter()
+                ctxs = [oavif_amd.Ssimu2(local_rank) for _ in range(fan)]
+                try:
+                    t2 = time.perf_counter()
+                    spec, st, _ = _tqs.search_speculative_hip(ctxs, ref, codec4k, score_tgt=80.0)
+                    t3 = time.perf_counter()
+                finally:
+                    for c_ in ctxs:
+                        c_.close()
+                out["search_end_to_end_4k"] = {
+                    "target": 80.0, "q": seq.q, "passes": seq.num_pass,
+                    "sequential_ms": round((t1 - t0) * 1e3, 1),
+                    "speculative_ms": round((t3 - t2) * 1e3, 1), "fanout": fan,
+                    "waves": st.waves, "probes_issued": st.probes_issued,
+                    "identical_result": bool((spec.q, spec.score, spec.history) ==
+                                             (seq.q, seq.score, seq.history)),
+                    "note": "Pillow libavif/aom speed 9 stands in for oavif's encoder; the "
+                            "speculative time includes uploading the reference to every context"}
+            except Exception as e:
+                out["search_end_to_end_4k"] = {"error": str(e)}
+
         # ---- quantizer match vs CPU: the same search (tq.zig:124-210) driven by the HIP scorer
         # and by the CPU oracle, same CPU codec, small frames so the oracle stays quick ---------
         if world == 1 and synth.have_avif() and not args.no_cpu_baseline:

@@ -313,8 +313,30 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
             cache[q] = data  # EncBuffer keeps only the last probe (tq.zig:31-35)
             return _decode_rgb(data), len(data)
 
-        r = tq.search_hip(scorer, rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
-                          max_pass=o.max_pass)
+        fan = int(os.environ.get("OAVIF_PROBE_FANOUT", "1") or 1)
+        if fan > 1 and own_scorer:
+            # probes of the search fanned over `fan` scorer contexts (HIP streams) and host
+            # threads (include/oavif_tq.h); same q, score and pass count as the plain search.
+            # Not a CLI flag: the option surface stays the reference's (parse_args.zig:76-122).
+            from . import Ssimu2
+            dev = int(os.environ.get("LOCAL_RANK", "0"))
+            ctxs = [scorer] + [Ssimu2(dev) for _ in range(min(fan, 16) - 1)]
+
+            def codec_keep(q: int):
+                data = _encode(src, o, q)
+                cache[q] = data  # every probe of a wave is kept: any of them may be the answer
+                return _decode_rgb(data), len(data)
+            try:
+                r, _stats, _sizes = tq.search_speculative_hip(
+                    ctxs, rgb, codec_keep, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                    max_pass=o.max_pass)
+            finally:
+                for c in ctxs[1:]:
+                    c.close()
+            r.buf_q = r.q if r.q in cache else r.buf_q
+        else:
+            r = tq.search_hip(scorer, rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                              max_pass=o.max_pass)
         eprint(f"Found q{r.q} (score {r.score:.2f}, {r.num_pass} passes)")
         data = cache.get(r.q) if r.buf_q == r.q else None
         if data is None:  # main.zig:109-113

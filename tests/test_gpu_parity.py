@@ -613,3 +613,21 @@ def test_speculative_search_with_real_avif_codec(hip_lib, scorer, seed, tgt):
             c.close()
     assert (res.q, res.score, res.num_pass, res.history) == (seq.q, seq.score, seq.num_pass, seq.history)
     assert stats.waves <= seq.num_pass
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+def test_cli_probe_fanout_env_gives_the_same_file_and_lines(hip_lib, tmp_path, capsys, monkeypatch):
+    """OAVIF_PROBE_FANOUT=N fans the probes of the CLI's search over N contexts; stderr lines
+    and the written AVIF are those of the plain run."""
+    from PIL import Image
+    from oavif_amd import cli
+    src = tmp_path / "in.png"
+    Image.fromarray(synth.make_ref(400, 304, 909)).save(src)
+    outs = []
+    for fan in ("1", "6"):
+        monkeypatch.setenv("OAVIF_PROBE_FANOUT", fan)
+        out = tmp_path / f"out{fan}.avif"
+        assert cli.main(["--score-tgt", "78", str(src), str(out)]) == 0
+        outs.append((capsys.readouterr().err.splitlines()[1:], out.read_bytes()))
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1]
