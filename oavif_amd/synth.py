@@ -96,12 +96,15 @@ def have_avif() -> bool:
         return False
 
 
-def avif_encode(rgb: np.ndarray, quality: int, speed: int = 9) -> bytes:
-    """CPU libavif/aom encode (YUV444) through Pillow; counterpart of io.zig:544."""
+def avif_encode(rgb: np.ndarray, quality: int, speed: int = 9, max_threads: int | None = None) -> bytes:
+    """CPU libavif/aom encode (YUV444) through Pillow; counterpart of io.zig:544.
+    max_threads: encoder threads (oavif's --max-threads, default 1 there: parse_args.zig:51);
+    None leaves Pillow's default (all cores)."""
     from PIL import Image
     buf = io.BytesIO()
+    kw = {} if max_threads is None else {"max_threads": int(max_threads)}
     Image.fromarray(rgb).save(buf, format="AVIF", quality=int(quality), subsampling="4:4:4",
-                              speed=int(speed))
+                              speed=int(speed), **kw)
     return buf.getvalue()
 
 
@@ -111,6 +114,6 @@ def avif_decode(data: bytes) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
 
 
-def avif_roundtrip(rgb: np.ndarray, quality: int, speed: int = 9):
-    data = avif_encode(rgb, quality, speed)
+def avif_roundtrip(rgb: np.ndarray, quality: int, speed: int = 9, max_threads: int | None = None):
+    data = avif_encode(rgb, quality, speed, max_threads)
     return avif_decode(data), len(data)
