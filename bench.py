@@ -219,6 +219,16 @@ def main() -> int:
                            "model": "SURVEY 8(d) W-model minus the pyramid writes: 77.97 B/px",
                            "blur_pyramid_frac_if_all_time_were_blur": round(
                                ALGO_BYTES_PER_PX_BLUR * w * h / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the same figure against the read-stream bandwidth this device delivers to a plain
+        # 16-byte-per-lane read kernel in the same run ("also report against a measured
+        # device-copy/read-stream ceiling"); rank 0 only, 2 GiB >> the 256 MB Infinity Cache
+        if rank == 0:
+            try:
+                stream_gbs = scorer.measure_read_stream(2 << 30, 10)
+                out["roofline"]["measured_read_stream_GBps"] = round(stream_gbs, 1)
+                out["roofline"]["frac_of_measured_read_stream"] = round(achieved / stream_gbs, 4)
+            except Exception as e:
+                out["roofline"]["measured_read_stream_GBps"] = f"error: {e}"
         # what actually bounds the kernel: VALU issue (counters from profiles/valu.json)
         vp = os.path.join(ROOT, "profiles", "valu.json")
         if os.path.exists(vp) and (w, h) == (W, H):

@@ -136,6 +136,13 @@ enum { SSIMU2_STAGE_PYRAMID = 0, SSIMU2_STAGE_MARCH = 1, SSIMU2_STAGE_FINALIZE =
 int ssimu2_time_stage(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
                       uint32_t h, int stage, int iters, float* out_ms_avg);
 
+/* Measurement aid: the HBM read-stream ceiling of the ctx's device, measured with a plain
+   grid-stride 16-byte-per-lane read kernel over a scratch buffer of `bytes` (use well over the
+   256 MB Infinity Cache, e.g. 2 GiB), `iters` launches on the ctx stream timed with HIP events.
+   *out_gbps = bytes / average launch time.  bench.py reports the kernels' achieved bandwidth
+   against this measured figure next to the nominal 8 TB/s. */
+int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double* out_gbps);
+
 /* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v1". */
 const char* ssimu2_version(void);
 

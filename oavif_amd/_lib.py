@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
     "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_debug_download", "ssimu2_time_device",
-    "ssimu2_time_stage",
+    "ssimu2_time_stage", "ssimu2_measure_read_stream",
     "ssimu2_version",
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
@@ -106,6 +106,8 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_set_reference.restype = ci
     L.ssimu2_score_against_reference.argtypes = [vp, u8p, f64p]
     L.ssimu2_score_against_reference.restype = ci
+    L.ssimu2_measure_read_stream.argtypes = [vp, ctypes.c_size_t, ci, f64p]
+    L.ssimu2_measure_read_stream.restype = ci
     L.ssimu2_score_against_reference_strided.argtypes = [vp, u8p, u32, u32, f64p]
     L.ssimu2_score_against_reference_strided.restype = ci
     L.ssimu2_set_reference_device.argtypes = [vp, vp, u32, u32]

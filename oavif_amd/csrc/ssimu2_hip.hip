@@ -708,4 +708,35 @@ int ssimu2_time_stage(ssimu2_ctx* c, const void* d_ref, const void* d_dist, uint
     return SSIMU2_OK;
 }
 
+int ssimu2_measure_read_stream(ssimu2_ctx* c, size_t bytes, int iters, double* out_gbps) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (bytes < (1u << 20) || iters <= 0 || !out_gbps)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad bytes/iters/out");
+    HIP_TRY(c, hipSetDevice(c->device));
+    void* buf = nullptr;
+    hipError_t e = hipMalloc(&buf, bytes + 64);
+    if (e != hipSuccess) return c->fail(SSIMU2_ERR_OOM, "hipMalloc(read-stream scratch)", e);
+    uint32_t* sink = (uint32_t*)((uint8_t*)buf + (bytes & ~(size_t)15));
+    int rc = SSIMU2_OK;
+    float ms = 0.f;
+    const size_t n16 = bytes / 16;
+    const int grid = 256 * 16;  // 16 workgroups of 4 waves per CU: the CUs' full wave capacity
+    if ((e = hipMemsetAsync(buf, 0, bytes + 64, c->stream)) != hipSuccess) goto hip_fail;
+    hipLaunchKernelGGL(k_read_stream, dim3(grid), dim3(256), 0, c->stream, (const uint4*)buf, n16, sink);
+    if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) goto hip_fail;
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_read_stream, dim3(grid), dim3(256), 0, c->stream, (const uint4*)buf, n16, sink);
+    if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) goto hip_fail;
+    if ((e = hipGetLastError()) != hipSuccess) goto hip_fail;
+    if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) goto hip_fail;
+    if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) goto hip_fail;
+    *out_gbps = (double)(n16 * 16) / ((double)ms / iters * 1e-3) * 1e-9;
+    (void)hipFree(buf);
+    return rc;
+hip_fail:
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    return c->fail(SSIMU2_ERR_HIP, "read-stream probe", e);
+}
+
 }  // extern "C"

@@ -176,6 +176,15 @@ class Ssimu2:
             self._raise(rc)
         return ms.value
 
+    def measure_read_stream(self, nbytes: int = 2 << 30, iters: int = 10) -> float:
+        """-> measured HBM read-stream bandwidth of the device in GB/s (ssimu2_measure_read_stream)."""
+        out = ctypes.c_double()
+        rc = self._L.ssimu2_measure_read_stream(self._ctx, ctypes.c_size_t(nbytes), iters,
+                                                ctypes.byref(out))
+        if rc != 0:
+            self._raise(rc)
+        return out.value
+
     def debug_download(self, what: int, scale: int, w: int, h: int) -> np.ndarray:
         """-> (3, h_s, w_s) float32 planes (see ssimu2_debug_download)."""
         sw, sh = w, h

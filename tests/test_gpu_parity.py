@@ -631,3 +631,16 @@ def test_cli_probe_fanout_env_gives_the_same_file_and_lines(hip_lib, tmp_path, c
         outs.append((capsys.readouterr().err.splitlines()[1:], out.read_bytes()))
     assert outs[0][0] == outs[1][0]
     assert outs[0][1] == outs[1][1]
+
+
+def test_read_stream_probe_reports_a_plausible_bandwidth(scorer):
+    """ssimu2_measure_read_stream: between 1 and 8 TB/s on an MI355X for a 1 GiB buffer, and the
+    context scores normally afterwards."""
+    gbs = scorer.measure_read_stream(1 << 30, 5)
+    assert 1000.0 < gbs < 8000.0
+    ref = synth.make_ref(64, 64, 5)
+    assert scorer.compute_ssimu2(ref, ref) == 100.0
+    from oavif_amd import Ssimu2Error, _lib
+    with pytest.raises(Ssimu2Error) as ei:
+        scorer.measure_read_stream(1024, 5)
+    assert ei.value.code == _lib.ERR_INVALID_ARG
