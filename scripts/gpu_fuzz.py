@@ -54,6 +54,17 @@ for i in range(n_cases):
     # the score magnifies relative error when it is far below zero (degenerate pairs reach
     # -1000): allow 1e-4 per 100 points of |score|
     ok = ns == ens and ds <= 1e-4 * max(1.0, abs(exp) / 100.0) and np.allclose(avg, eavg, rtol=2e-5, atol=1e-9)
+    # the other entry points on the same pair must give the same bits: cached reference, and the
+    # decoded-frame hand-off from a random RGB/RGBA layout with random row padding
+    s.set_reference(ref)
+    ch, pad = int(rng.integers(3, 5)), int(rng.integers(0, 3)) * int(rng.integers(0, 9))
+    pitch = w * ch + pad
+    buf = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    view = np.lib.stride_tricks.as_strided(buf, (h, w, ch), (pitch, ch, 1))
+    view[..., :3] = dist
+    same = (s.score_against_reference(dist) == got and s.score_decoded_against_reference(view) == got
+            and np.array_equal(orc.copy_rgb_pixels(view), dist))
+    ok = ok and same
     if not ok:
         bad.append((i, w, h, int(kind), int(dk), got, exp, ns, ens))
 print(f"{n_cases} cases in {time.time()-t0:.1f}s: worst |dscore| = {worst_score:.3e}, worst rel avg dev (atol-free) = {worst_avg:.3e}, violations = {len(bad)}")
