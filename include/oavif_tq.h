@@ -126,6 +126,19 @@ int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
                                              oavif_tq_batch_probe_fn batch, void* user,
                                              oavif_tq_result* out, oavif_tq_spec_stats* stats);
 
+/* ---- source pre-scaling, hoisted out of the pass loop ------------------------------------
+ *
+ * io.encodeAvifToBuffer rescales the whole source to the output depth on EVERY pass
+ * (io.zig:566-617: a fresh w*h*channels buffer and one loop over it), although the source
+ * never changes during a search -- only `quality` does (io.zig:625).  These are the three
+ * loops as functions, so that a caller computes the scaled buffer once per search and hands
+ * the same pointer to avifImageRGBToYUV on every pass.  Integer
+ * arithmetic, identical values.  `n` = w * h * channels elements.
+ */
+void oavif_prescale_8_to_10(const uint8_t* src, size_t n, uint16_t* dst);   /* (v*1023+127)/255  io.zig:572 */
+void oavif_prescale_16_to_10(const uint16_t* src, size_t n, uint16_t* dst); /* v >> 6            io.zig:587 */
+void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v >> 8            io.zig:602 */
+
 #ifdef __cplusplus
 }
 #endif

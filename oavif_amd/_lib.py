@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
     "oavif_tq_find_target_quality_speculative",
+    "oavif_prescale_8_to_10", "oavif_prescale_16_to_10", "oavif_prescale_16_to_8",
 )
 
 
@@ -144,6 +145,13 @@ def lib() -> ctypes.CDLL:
         ctypes.POINTER(TQOptions), ctypes.POINTER(TQSpecOptions), BATCH_PROBE_FN, vp,
         ctypes.POINTER(TQResult), ctypes.POINTER(TQSpecStats)]
     L.oavif_tq_find_target_quality_speculative.restype = ci
+    u16p = ctypes.POINTER(ctypes.c_uint16)
+    L.oavif_prescale_8_to_10.argtypes = [u8p, ctypes.c_size_t, u16p]
+    L.oavif_prescale_8_to_10.restype = None
+    L.oavif_prescale_16_to_10.argtypes = [u16p, ctypes.c_size_t, u16p]
+    L.oavif_prescale_16_to_10.restype = None
+    L.oavif_prescale_16_to_8.argtypes = [u16p, ctypes.c_size_t, u8p]
+    L.oavif_prescale_16_to_8.restype = None
     L.oavif_tq_search_hip.argtypes = [ctypes.POINTER(TQOptions), vp, u8p, u32, u32, CODEC_FN, vp,
                                       ctypes.POINTER(TQResult), ctypes.POINTER(ctypes.c_size_t)]
     L.oavif_tq_search_hip.restype = ci

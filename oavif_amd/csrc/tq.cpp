@@ -345,4 +345,19 @@ int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uin
     return rc;
 }
 
+// io.zig:566-617 as functions of the source alone (see the header): computed once per search.
+void oavif_prescale_8_to_10(const uint8_t* src, size_t n, uint16_t* dst) {
+    uint16_t lut[256];
+    for (unsigned v = 0; v < 256; ++v) lut[v] = (uint16_t)((v * 1023u + 127u) / 255u);  // io.zig:572
+    for (size_t i = 0; i < n; ++i) dst[i] = lut[src[i]];
+}
+
+void oavif_prescale_16_to_10(const uint16_t* src, size_t n, uint16_t* dst) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (uint16_t)(src[i] >> 6);  // io.zig:587
+}
+
+void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (uint8_t)(src[i] >> 8);  // io.zig:602
+}
+
 }  // extern "C"

@@ -190,3 +190,26 @@ def search_hip(scorer: Ssimu2, ref_rgb: np.ndarray,
     out = _result(res)
     out.last_avif_size = int(last.value)
     return out
+
+
+def prescale(src: np.ndarray, out_depth: int) -> np.ndarray:
+    """The source rescaled to the encoder's depth as io.encodeAvifToBuffer does on every pass
+    (io.zig:566-617), to be computed once per search (include/oavif_tq.h).  src uint8 or uint16
+    (full 16-bit range); out_depth 8 or 10."""
+    L = _lib.lib()
+    a = np.ascontiguousarray(src)
+    u8p, u16p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint16)
+    if a.dtype == np.uint8 and out_depth == 10:
+        out = np.empty(a.shape, np.uint16)
+        L.oavif_prescale_8_to_10(a.ctypes.data_as(u8p), a.size, out.ctypes.data_as(u16p))
+    elif a.dtype == np.uint16 and out_depth == 10:
+        out = np.empty(a.shape, np.uint16)
+        L.oavif_prescale_16_to_10(a.ctypes.data_as(u16p), a.size, out.ctypes.data_as(u16p))
+    elif a.dtype == np.uint16 and out_depth == 8:
+        out = np.empty(a.shape, np.uint8)
+        L.oavif_prescale_16_to_8(a.ctypes.data_as(u16p), a.size, out.ctypes.data_as(u8p))
+    elif a.dtype == np.uint8 and out_depth == 8:
+        out = a  # io.zig:609-612: the source is handed over as it is
+    else:
+        raise ValueError("src must be uint8 or uint16, out_depth 8 or 10")
+    return out

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b((?:ssimu2|oavif_tq)_[a-z0-9_]+)\s*\(", text)
+    names = re.findall(r"\b((?:ssimu2|oavif)_[a-z0-9_]+)\s*\(", text)
     # drop typedef'd function-pointer types
     return sorted({n for n in names if not n.endswith("_fn")})
 

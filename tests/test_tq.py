@@ -272,3 +272,20 @@ def test_speculation_saves_waves_on_typical_curves(tq):
         passes += res.num_pass
         waves += stats.waves
     assert waves < 0.85 * passes
+
+
+# ---- pre-scaling hoist (io.zig:566-617 as functions) -------------------------
+def test_prescale_matches_the_reference_formulas_on_every_value(tq):
+    import numpy as np
+    v8 = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(tq.prescale(v8, 10), (v8.astype(np.uint64) * 1023 + 127) // 255)   # io.zig:572
+    assert tq.prescale(v8, 10).dtype == np.uint16 and tq.prescale(v8, 10)[-1] == 1023
+    assert tq.prescale(v8, 8) is not None and np.array_equal(tq.prescale(v8, 8), v8)        # io.zig:609
+    v16 = np.arange(65536, dtype=np.uint16)
+    assert np.array_equal(tq.prescale(v16, 10), v16 >> 6)                                     # io.zig:587
+    assert np.array_equal(tq.prescale(v16, 8), (v16 >> 8).astype(np.uint8))                   # io.zig:602
+    img = np.random.default_rng(3).integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    out = tq.prescale(img, 10)
+    assert out.shape == img.shape and np.array_equal(out, (img.astype(np.uint32) * 1023 + 127) // 255)
+    with pytest.raises(ValueError):
+        tq.prescale(img.astype(np.float32), 10)
