@@ -290,7 +290,7 @@ void launch_pyramid(ssimu2_ctx* c, const Pyramid& p, int nframes, const uint8_t*
             a.in[f] = base == 0 ? (const void*)frames[f] : (const void*)(lin[f] + p.lin_off[base]);
             for (int k = 0; k < n; ++k) a.out[f][k] = lin[f] + p.lin_off[base + 1 + k];
         }
-        dim3 grid((a.w[1] + 31) / 32, (a.h[1] + 31) / 32, nframes), block(256);
+        dim3 grid((a.w[1] + 31) / 32, (a.h[1] + PYR_TILE_H - 1) / PYR_TILE_H, nframes), block(256);
         if (base == 0) hipLaunchKernelGGL(k_pyramid<true>, grid, block, 0, c->stream, a);
         else hipLaunchKernelGGL(k_pyramid<false>, grid, block, 0, c->stream, a);
     }

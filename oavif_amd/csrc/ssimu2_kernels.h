@@ -154,9 +154,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---- linear-light pyramid ----------------------------------------------------------------------
 // out(ox,oy) = (((p00 + p01) + p10) + p11) * 0.25 with coordinates clamped to the last
 // row/column of the level above (the published Downsample(in, 2, 2)).  One workgroup reads a
-// 64x64 tile of the input level once and emits the 32x32, 16x16 and 8x8 tiles of the next
+// 64x32 tile of the input level once and emits the 32x16, 16x8 and 8x4 tiles of the next
 // three levels (tiles are aligned to powers of two, so every 2x2 source block, clamped or
 // not, lies inside the tile).  blockIdx.z selects the frame.
+// A workgroup covers 32 x 16 outputs of the first produced level (9 KB of LDS, <= 32 VGPRs):
+// small enough to be co-resident with three k_march workgroups on a CU (3 x 49.3 KB of the
+// 160 KB LDS, 480 of 512 VGPRs per SIMD), so that with two streams the HBM-bound pyramid of one
+// score really runs under the VALU-bound marching kernel of another.
 struct PyramidArgs {
     const void* in[2];   // per frame: u8 interleaved RGB (level 0) or fp32 planes [3][h][w]
     float* out[2][3];    // per frame, per produced level: fp32 planes; null = not produced
@@ -164,21 +168,23 @@ struct PyramidArgs {
     int nlevels;         // 1..3 levels to produce
 };
 
+constexpr int PYR_TILE_H = 16;  // rows of the first produced level per workgroup (multiple of 8)
+
 template <bool kU8>
 __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
-    __shared__ float s1[3][32][33];
-    __shared__ float s2[3][16][17];
+    __shared__ float s1[3][PYR_TILE_H][33];
+    __shared__ float s2[3][PYR_TILE_H / 2][17];
     __shared__ float s_lut[256];
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
     if (kU8) s_lut[tid] = c_k.lut[tid];
     if (kU8) __syncthreads();
     const int w0 = a.w[0], h0 = a.h[0], w1 = a.w[1], h1 = a.h[1];
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;  // tile origin at level +1
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * PYR_TILE_H;  // tile origin at level +1
     const size_t n0 = (size_t)w0 * h0, n1 = (size_t)w1 * h1;
-    // level +1: 1024 outputs, 4 per thread
+    // level +1: 32 x PYR_TILE_H outputs, PYR_TILE_H / 8 per thread
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PYR_TILE_H / 8; ++j) {
         const int lx = tid & 31, ly = (tid >> 5) + 8 * j;
         const int ox = tx0 + lx, oy = ty0 + ly;
         float v[3] = {0.f, 0.f, 0.f};
@@ -220,9 +226,9 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
     }
     if (a.nlevels < 2) return;
     __syncthreads();
-    // level +2: 16x16 outputs, one per thread
+    // level +2: 16 x PYR_TILE_H/2 outputs, one per thread
     const int w2 = a.w[2], h2 = a.h[2];
-    {
+    if (tid < 16 * (PYR_TILE_H / 2)) {
         const int lx = tid & 15, ly = tid >> 4;
         const int ox = (tx0 >> 1) + lx, oy = (ty0 >> 1) + ly;
         float v[3] = {0.f, 0.f, 0.f};
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
     }
     if (a.nlevels < 3) return;
     __syncthreads();
-    // level +3: 8x8 outputs
-    if (tid < 64) {
+    // level +3: 8 x PYR_TILE_H/4 outputs
+    if (tid < 8 * (PYR_TILE_H / 4)) {
         const int w3 = a.w[3], h3 = a.h[3];
         const int lx = tid & 7, ly = tid >> 3;
         const int ox = (tx0 >> 2) + lx, oy = (ty0 >> 2) + ly;
