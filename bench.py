@@ -294,7 +294,7 @@ def main() -> int:
         # decoded-frame hand-off: libavif's RGBA rows scored as they are
         # (alpha dropped on the device) vs the reference's CPU copy loop (io.zig:654-663, timed
         # through the oracle's restatement) followed by the tight-RGB pass above
-        rgba = np.concatenate([dst, np.full((H, W, 1), 255, np.uint8)], axis=2)
+        rgba = np.concatenate([dst, np.full((h, w, 1), 255, np.uint8)], axis=2)
         s_rgba = scorer.score_decoded_against_reference(rgba)
         tt = time.perf_counter()
         for _ in range(n_pass):
