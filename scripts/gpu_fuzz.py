@@ -65,6 +65,8 @@ for i in range(n_cases):
     same = (s.score_against_reference(dist) == got and s.score_decoded_against_reference(view) == got
             and np.array_equal(orc.copy_rgb_pixels(view), dist))
     ok = ok and same
+    if (i + 1) % 1000 == 0:  # a silent run of several minutes is taken for a hang on the GPU box
+        print(f"  {i + 1} cases, worst |dscore| {worst_score:.3e}, violations {len(bad)}", flush=True)
     if not ok:
         bad.append((i, w, h, int(kind), int(dk), got, exp, ns, ens))
 print(f"{n_cases} cases in {time.time()-t0:.1f}s: worst |dscore| = {worst_score:.3e}, worst rel avg dev (atol-free) = {worst_avg:.3e}, violations = {len(bad)}")
