@@ -1,3 +1,4 @@
+"""HBM read-stream ceiling (ssimu2_measure_read_stream) for 1, 2 and 4 GiB buffers, three runs each."""
 import sys; sys.path.insert(0,'.')
 import oavif_amd
 with oavif_amd.Ssimu2(0) as s:
