@@ -1,7 +1,7 @@
 """GPU-box diagnostic: HIP vs oracle deviations (scores and the 108 averages)."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oavif_amd
 from oavif_amd import synth

@@ -3,7 +3,7 @@ random sizes, contents and distortions.  Prints the worst deviations; exits 1 on
 of the test tolerances (|dscore| <= 1e-4 per 100 points of |score|, averages rtol 2e-5)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oavif_amd
 from oavif_amd import synth
