@@ -242,7 +242,12 @@ def load_image(path: str):
         rgb = np.repeat(arr[..., :1], 3, axis=2)
     else:
         rgb = arr[..., :3]
+    global _src_icc  # Image.icc (io.zig:48): handed to the encoder unchanged (io.zig:556-560)
+    _src_icc = None if ext == ".pam" else im.info.get("icc_profile")
     return np.ascontiguousarray(rgb), arr, ch, hbd
+
+
+_src_icc = None
 
 
 def _encode(src, o: AvifEncOptions, q: int) -> bytes:
@@ -252,8 +257,9 @@ def _encode(src, o: AvifEncOptions, q: int) -> bytes:
     mode = {1: "L", 2: "LA", 3: "RGB", 4: "RGBA"}[src.shape[2]]
     im = Image.fromarray(src[..., 0] if src.shape[2] == 1 else src, mode)
     buf = _io.BytesIO()
+    extra = {"icc_profile": _src_icc} if _src_icc else {}
     im.save(buf, format="AVIF", quality=int(q), subsampling="4:4:4", speed=o.speed,
-            max_threads=o.max_threads, tile_rows=o.tile_rows_log2, tile_cols=o.tile_cols_log2,
+            max_threads=o.max_threads, **extra, tile_rows=o.tile_rows_log2, tile_cols=o.tile_cols_log2,
             autotiling=o.auto_tiling, advanced={"tune": o.tune} if o.tune == "ssim" else None)
     return buf.getvalue()
 

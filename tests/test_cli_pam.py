@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from oavif_amd import cli, pam
+from oavif_amd import cli, pam, synth
 
 
 def parse(*argv):
@@ -141,3 +141,22 @@ def test_to_rgb8_rules(tmp_path):
     with pytest.raises(cli.CliError) as ei:
         cli.load_image("x.bmp")
     assert ei.value.name == "UnsupportedImageFormat"
+
+
+@pytest.mark.skipif(not synth.have_avif(), reason="Pillow AVIF codec not available")
+def test_icc_profile_passes_through_the_quality_bypass(tmp_path, capsys):
+    """io.zig:556-560: the source's ICC profile is handed to the encoder unchanged (checked on the
+    -q path, which needs no scorer)."""
+    from PIL import Image, ImageCms
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+    src = tmp_path / "in.png"
+    Image.fromarray(synth.make_ref(64, 48, 5)).save(src, icc_profile=icc)
+    out = tmp_path / "out.avif"
+    assert cli.main(["-q", "70", str(src), str(out)]) == 0
+    capsys.readouterr()
+    assert Image.open(out).info.get("icc_profile") == icc
+    plain = tmp_path / "plain.png"
+    Image.fromarray(synth.make_ref(64, 48, 5)).save(plain)
+    assert cli.main(["-q", "70", str(plain), str(out)]) == 0
+    capsys.readouterr()
+    assert not Image.open(out).info.get("icc_profile")
