@@ -53,6 +53,14 @@ enum {
    hipStream_t owned by the caller that all work of this ctx is enqueued on; if NULL the
    ctx creates (and later destroys) its own non-blocking stream. */
 int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx);
+
+/* Optional: start the once-per-process initialisation of `device` (HIP runtime, code object,
+   constant table -- 140-340 ms) on a background thread and return at once.  A later
+   ssimu2_ctx_create for that device waits for it and is then quick.  Meant for one-image runs
+   such as the oavif CLI: call it first thing in main(), and the cost disappears behind the image
+   load and the first encode (main.zig:62-101, tq.zig:24).  Harmless to call twice or without a
+   GPU (ssimu2_ctx_create then reports SSIMU2_ERR_NO_DEVICE as usual). */
+int ssimu2_prefetch(int device);
 void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
 
 /* Human-readable description of the last error on this ctx ("" if none).  The pointer

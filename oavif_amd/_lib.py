@@ -26,7 +26,7 @@ TQ_MAX_PASS = 12
 
 # every symbol the headers declare; tests/test_abi.py checks the .so exports all of them
 EXPORTED_SYMBOLS = (
-    "ssimu2_ctx_create", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
+    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
     "ssimu2_set_reference", "ssimu2_score_against_reference",
     "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
@@ -97,6 +97,8 @@ def lib() -> ctypes.CDLL:
     u32, ci = ctypes.c_uint32, ctypes.c_int
     L.ssimu2_ctx_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
     L.ssimu2_ctx_create.restype = ci
+    L.ssimu2_prefetch.argtypes = [ci]
+    L.ssimu2_prefetch.restype = ci
     L.ssimu2_ctx_destroy.argtypes = [vp]
     L.ssimu2_ctx_destroy.restype = None
     L.ssimu2_last_error.argtypes = [vp]

@@ -291,6 +291,13 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
     own_scorer = False
     try:
         o, inp, out = parse_args(argv)
+        if scorer is None and o.quality is None and inp is not None and out is not None:
+            # a search will need the scorer: start its once-per-process initialisation (HIP
+            # runtime, code object: 0.15-0.35 s) now, behind the image load and the first encode
+            if "torch" not in sys.modules:
+                os.environ.setdefault("OAVIF_AMD_NO_TORCH", "1")  # a CLI run shares nothing with torch
+            from . import _lib
+            _lib.lib().ssimu2_prefetch(int(os.environ.get("LOCAL_RANK", "0")))
         if inp is None or out is None:
             raise CliError("MissingInputOrOutput")
         rgb, src, channels, hbd = load_image(inp)

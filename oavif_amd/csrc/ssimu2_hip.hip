@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <future>
 #include <mutex>
 #include <new>
 #include <string>
@@ -382,7 +383,42 @@ const char* ssimu2_last_error(const ssimu2_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx);
+
+// ssimu2_prefetch: the once-per-process cost of the scorer (HIP runtime initialisation, loading
+// the code object, the constant table: 140-340 ms on the MI355X box, scripts/gpu_coldstart.py) on
+// a background thread, so that a one-image run hides it behind its image load and first encode.
+static std::mutex g_prefetch_mu;
+static std::shared_future<void> g_prefetch[64];
+
+int ssimu2_prefetch(int device) {
+    if (device < 0 || device >= 64) return SSIMU2_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g_prefetch_mu);
+    if (g_prefetch[device].valid()) return SSIMU2_OK;
+    try {
+        g_prefetch[device] = std::async(std::launch::async, [device] {
+            ssimu2_ctx* tmp = nullptr;  // a throw-away context does all of the above
+            if (ctx_create_impl(device, nullptr, &tmp) == SSIMU2_OK) ssimu2_ctx_destroy(tmp);
+        }).share();
+    } catch (...) {
+        return SSIMU2_ERR_OOM;
+    }
+    return SSIMU2_OK;
+}
+
 int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
+    if (device >= 0 && device < 64) {
+        std::shared_future<void> f;
+        {
+            std::lock_guard<std::mutex> lock(g_prefetch_mu);
+            f = g_prefetch[device];
+        }
+        if (f.valid()) f.wait();  // a prefetch in flight finishes first
+    }
+    return ctx_create_impl(device, hip_stream, out_ctx);
+}
+
+static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     if (!out_ctx) return SSIMU2_ERR_INVALID_ARG;
     *out_ctx = nullptr;
     int ndev = 0;

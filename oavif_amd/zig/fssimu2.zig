@@ -29,6 +29,7 @@ pub const Error = error{
 const Ctx = opaque {};
 
 extern fn ssimu2_ctx_create(device: c_int, hip_stream: ?*anyopaque, out_ctx: *?*Ctx) c_int;
+extern fn ssimu2_prefetch(device: c_int) c_int;
 extern fn ssimu2_ctx_destroy(ctx: ?*Ctx) void;
 extern fn ssimu2_last_error(ctx: ?*const Ctx) [*:0]const u8;
 extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: u32, h: u32, channels: u32, out_score: *f64) c_int;
@@ -71,6 +72,13 @@ fn context() Error!*Ctx {
     try check(ssimu2_ctx_create(device, null, &c));
     g_ctx = c;
     return c.?;
+}
+
+/// Optional, for one-image runs: start the once-per-process GPU initialisation (0.15-0.35 s) on
+/// a background thread; call it first thing in main() and the cost hides behind io.loadImage and
+/// the first encode (INTEGRATION.md section 2d).
+pub fn prefetch() void {
+    _ = ssimu2_prefetch(device);
 }
 
 /// Release the GPU context (optional; the process exit does it too).

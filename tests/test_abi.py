@@ -65,3 +65,17 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "ssimu2_oracle" not in text and "tq_oracle" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_prefetch_without_a_gpu_is_harmless(hip_lib):
+    """ssimu2_prefetch starts the per-process initialisation on a background thread; on a box
+    without a GPU it must return at once and leave ssimu2_ctx_create's error behaviour alone."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    from oavif_amd import _lib
+    assert hip_lib.ssimu2_prefetch(0) == 0
+    assert hip_lib.ssimu2_prefetch(0) == 0            # idempotent
+    assert hip_lib.ssimu2_prefetch(-1) == _lib.ERR_INVALID_ARG
+    ctx = ctypes.c_void_p()
+    assert hip_lib.ssimu2_ctx_create(0, None, ctypes.byref(ctx)) == _lib.ERR_NO_DEVICE

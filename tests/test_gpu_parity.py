@@ -644,3 +644,12 @@ def test_read_stream_probe_reports_a_plausible_bandwidth(scorer):
     with pytest.raises(Ssimu2Error) as ei:
         scorer.measure_read_stream(1024, 5)
     assert ei.value.code == _lib.ERR_INVALID_ARG
+
+
+def test_prefetch_then_create_scores_normally(hip_lib):
+    import oavif_amd
+    assert hip_lib.ssimu2_prefetch(0) == 0
+    assert hip_lib.ssimu2_prefetch(0) == 0
+    ref = synth.make_ref(96, 64, 2)
+    with oavif_amd.Ssimu2(0) as s:                     # waits for the prefetch, then is quick
+        assert s.compute_ssimu2(ref, ref) == 100.0
