@@ -56,6 +56,10 @@
 #define OR_NUM_SCALES 6
 #define OR_BLUR_IIR 0
 #define OR_BLUR_FIR 1
+#define OR_BLUR_IIR_FMA 3 /* OR_BLUR_IIR with the recursion's multiply-subtract fused (what an FMA
+                             target of libjxl's MulAdd evaluates): a second, equally legitimate
+                             fp32 evaluation order, kept only to measure how far two recursive
+                             implementations differ from EACH OTHER (tests/tools/) */
 #define OR_BLUR_EXACT 2 /* the same 9-tap operator accumulated in fp64, result rounded to fp32:
                           what both fp32 forms approximate (evidence for DESIGN.md 2.1) */
 
@@ -175,7 +179,7 @@ void or_gauss_taps(double* taps5_f64, float* taps5_f32, double* n2_3, double* d1
 
 /* 1-D recursive pass over a strided line (scalar form of libjxl FastGaussian1D). */
 static void iir_line(const or_gauss* rg, const float* in, ptrdiff_t n_in, ptrdiff_t stride_in,
-                     float* out, ptrdiff_t stride_out) {
+                     float* out, ptrdiff_t stride_out, int fused) {
     const ptrdiff_t N = rg->radius;
     const float n2_1 = rg->n2[0], n2_3 = rg->n2[1], n2_5 = rg->n2[2];
     const float d1_1 = rg->d1[0], d1_3 = rg->d1[1], d1_5 = rg->d1[2];
@@ -189,9 +193,15 @@ static void iir_line(const or_gauss* rg, const float* in, ptrdiff_t n_in, ptrdif
         o1 = o1 - prev2_1;
         o3 = o3 - prev2_3;
         o5 = o5 - prev2_5;
-        o1 = o1 - d1_1 * prev_1;
-        o3 = o3 - d1_3 * prev_3;
-        o5 = o5 - d1_5 * prev_5;
+        if (fused) {
+            o1 = fmaf(-d1_1, prev_1, o1);
+            o3 = fmaf(-d1_3, prev_3, o3);
+            o5 = fmaf(-d1_5, prev_5, o5);
+        } else {
+            o1 = o1 - d1_1 * prev_1;
+            o3 = o3 - d1_3 * prev_3;
+            o5 = o5 - d1_5 * prev_5;
+        }
         prev2_1 = prev_1; prev2_3 = prev_3; prev2_5 = prev_5;
         prev_1 = o1; prev_3 = o3; prev_5 = o5;
         if (n >= 0) out[n * stride_out] = o1 + o3 + o5;
@@ -275,19 +285,21 @@ static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, 
                        float* tmp, float* out) {
 #pragma omp parallel for schedule(static)
     for (ptrdiff_t y = 0; y < (ptrdiff_t)h; ++y) {
-        if (mode == OR_BLUR_IIR) iir_line(rg, in + y * w, w, 1, tmp + y * w, 1);
+        if (mode == OR_BLUR_IIR || mode == OR_BLUR_IIR_FMA)
+            iir_line(rg, in + y * w, w, 1, tmp + y * w, 1, mode == OR_BLUR_IIR_FMA);
         else fir_line(rg, in + y * w, w, 1, tmp + y * w, 1);
     }
 #pragma omp parallel for schedule(static)
     for (ptrdiff_t x = 0; x < (ptrdiff_t)w; ++x) {
-        if (mode == OR_BLUR_IIR) iir_line(rg, tmp + x, h, w, out + x, w);
+        if (mode == OR_BLUR_IIR || mode == OR_BLUR_IIR_FMA)
+            iir_line(rg, tmp + x, h, w, out + x, w, mode == OR_BLUR_IIR_FMA);
         else fir_line(rg, tmp + x, h, w, out + x, w);
     }
 }
 
 static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const float* b, size_t w,
                             size_t h, float* prod_tmp, float* tmp, float* out) {
-    if (mode == OR_BLUR_IIR) {
+    if (mode == OR_BLUR_IIR || mode == OR_BLUR_IIR_FMA) {
         const size_t n = w * h;
 #pragma omp parallel for schedule(static)
         for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) prod_tmp[i] = a[i] * b[i];
