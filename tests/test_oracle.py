@@ -254,3 +254,18 @@ def test_copy_rgb_pixels_drops_alpha_and_padding(oracle):
         buf = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
         view = np.lib.stride_tricks.as_strided(buf, (h, w, ch), (pitch, ch, 1))
         assert np.array_equal(oracle.copy_rgb_pixels(view), view[..., :3])
+
+
+def test_second_recursive_evaluation_order_is_a_different_but_close_score(oracle, golden):
+    """BLUR_IIR_FMA fuses the recursion's multiply-subtract: same operator, another fp32 rounding
+    sequence.  The two recursive orders must differ in bits yet stay within the spread the
+    recursion's noise allows (max 0.34 points over 421 AVIF probes)."""
+    arrays, meta = golden
+    ref = arrays["ref"]
+    diffs = []
+    for p in meta["pairs"]:
+        a = oracle.compute_ssimu2(ref, arrays[p["name"]], oracle.BLUR_IIR)
+        b = oracle.compute_ssimu2(ref, arrays[p["name"]], oracle.BLUR_IIR_FMA)
+        diffs.append(abs(a - b))
+    assert max(diffs) > 0.0
+    assert max(diffs) < 1.0
