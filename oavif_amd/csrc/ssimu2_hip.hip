@@ -134,6 +134,8 @@ struct ssimu2_ctx {
     float* d_lin_ref = nullptr;   // scales 1..5 packed
     float* d_lin_dist = nullptr;
     float* d_xyb_ref = nullptr;   // cached positive-XYB planes of the reference, all scales
+    float* d_ref_blur = nullptr;  // cached blur(ref) then blur(ref*ref) planes, all scales
+    size_t cap_blur = 0;          // floats per plane set (0 = not cached)
     uint8_t* d_stage = nullptr;   // decoded avifRGBImage as uploaded (RGBA / padded rows)
     size_t cap_stage = 0;
     size_t cap_xyb = 0;
@@ -241,6 +243,9 @@ void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_stage);
     c->d_stage = nullptr;
     c->cap_stage = 0;
+    (void)hipFree(c->d_ref_blur);
+    c->d_ref_blur = nullptr;
+    c->cap_blur = 0;
     c->d_ref_u8 = c->d_dist_u8 = nullptr;
     c->d_lin_ref = c->d_lin_dist = nullptr;
     c->d_partials = nullptr;
@@ -325,6 +330,9 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
         mp->ref[s] = s == 0 ? (const void*)d_ref : (const void*)(c->d_lin_ref + p.lin_off[s]);
         mp->dist[s] = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
         mp->ref_xyb[s] = ref_xyb_cached ? c->d_xyb_ref + xyb_off(p, s) : nullptr;
+        const bool blur_cached = ref_xyb_cached && c->d_ref_blur && c->cap_blur;
+        mp->ref_mu[s] = blur_cached ? c->d_ref_blur + xyb_off(p, s) : nullptr;
+        mp->ref_s11[s] = blur_cached ? c->d_ref_blur + c->cap_blur + xyb_off(p, s) : nullptr;
         mp->part[s] = c->d_partials + poff;
         fa->part[s] = mp->part[s];
         fa->nblocks[s] = nb;
@@ -354,8 +362,12 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
     FinalizeArgs fa;
     int blocks = 0;
     build_plans(c, p, d_ref, d_dist, ref_pyramid_ready && c->d_xyb_ref != nullptr, &mp, &fa, &blocks);
-    if (blocks > 0)
-        hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+    if (blocks > 0) {
+        if (mp.ref_mu[0])  // reference XYB and blur planes cached: the search's per-pass kernel
+            hipLaunchKernelGGL(k_march_refblur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+        else
+            hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+    }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, 110 * sizeof(double),
@@ -579,6 +591,35 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
             hipLaunchKernelGGL(k_ref_xyb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in,
                                sc == 0, p.w[sc], p.h[sc], c->d_xyb_ref + xyb_off(p, sc));
         }
+    }
+    // ... and the two blur planes that depend on the reference alone, blur(ref) and
+    // blur(ref*ref), at every scale: the per-pass kernel then blurs three planes instead of five
+    if (c->d_xyb_ref && getenv("OAVIF_AMD_NO_REF_BLUR") == nullptr) {
+        if (need_xyb > c->cap_blur) {
+            (void)hipFree(c->d_ref_blur);
+            c->d_ref_blur = nullptr;
+            c->cap_blur = 0;
+            hipError_t e = hipMalloc(&c->d_ref_blur, 2 * need_xyb * sizeof(float));
+            if (e != hipSuccess) {  // not fatal either: the pass blurs all five planes
+                c->d_ref_blur = nullptr;
+                (void)hipGetLastError();
+            } else {
+                c->cap_blur = need_xyb;
+            }
+        }
+        if (c->d_ref_blur) {
+            MarchPlan mp;
+            FinalizeArgs fa;
+            int blocks = 0;
+            build_plans(c, p, c->d_ref_u8, c->d_ref_u8, true, &mp, &fa, &blocks);
+            for (int sc = 0; sc < p.nscales; ++sc) mp.dist[sc] = mp.ref[sc];  // second frame unused
+            if (blocks > 0)
+                hipLaunchKernelGGL(k_ref_blur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+        }
+    } else if (c->d_ref_blur) {
+        (void)hipFree(c->d_ref_blur);
+        c->d_ref_blur = nullptr;
+        c->cap_blur = 0;
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `ref` after return
