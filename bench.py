@@ -307,7 +307,7 @@ def main() -> int:
         c_ms = (time.perf_counter() - tt) / n_c * 1e3
         out["cached_reference"] = {"ms_per_score": round(c_ms, 5), "MP_per_s": round(mp / c_ms * 1e3, 1),
                                    "bit_identical_to_pair_score": bool(c_score == scores[0]),
-                                   "note": "reference pyramid, XYB and blur planes cached by ssimu2_set_reference; "
+                                   "note": "reference pyramid, XYB and blur(ref^2) planes cached by ssimu2_set_reference; "
                                            "one stream; separate from `value`"}
 
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------

@@ -78,9 +78,9 @@ int ssimu2_score_rgb8(ssimu2_ctx* ctx, const uint8_t* ref, const uint8_t* dist, 
    e.rgb on every pass, main.zig:86).  set_reference uploads `ref` once and keeps only
    device copies (its linear-light pyramid); score_against_reference then uploads and
    scores one `dist`.  Besides the linear-light pyramid, the reference's positive-XYB planes and
-   the two blurred planes that depend on the reference alone (blur(ref), blur(ref*ref)) are cached
-   at every scale, so each pass skips the colour conversion of the reference frame and two of the
-   five blurs (about 0.4 GB of device memory per context at 4K).
+   blur(ref*ref) -- one of the five blurs, which depends on the reference alone -- are cached at
+   every scale, so each pass skips the colour conversion of the reference frame and that blur
+   (about 0.3 GB of device memory per context at 4K).
    Results are bit-identical to ssimu2_score_rgb8 on the same pair. */
 int ssimu2_set_reference(ssimu2_ctx* ctx, const uint8_t* ref, uint32_t w, uint32_t h);
 int ssimu2_score_against_reference(ssimu2_ctx* ctx, const uint8_t* dist, double* out_score);

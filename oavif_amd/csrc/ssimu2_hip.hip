@@ -134,8 +134,8 @@ struct ssimu2_ctx {
     float* d_lin_ref = nullptr;   // scales 1..5 packed
     float* d_lin_dist = nullptr;
     float* d_xyb_ref = nullptr;   // cached positive-XYB planes of the reference, all scales
-    float* d_ref_blur = nullptr;  // cached blur(ref) then blur(ref*ref) planes, all scales
-    size_t cap_blur = 0;          // floats per plane set (0 = not cached)
+    float* d_ref_blur = nullptr;  // cached blur(ref*ref) planes, all scales
+    size_t cap_blur = 0;          // floats allocated (0 = not cached)
     uint8_t* d_stage = nullptr;   // decoded avifRGBImage as uploaded (RGBA / padded rows)
     size_t cap_stage = 0;
     size_t cap_xyb = 0;
@@ -331,8 +331,7 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
         mp->dist[s] = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
         mp->ref_xyb[s] = ref_xyb_cached ? c->d_xyb_ref + xyb_off(p, s) : nullptr;
         const bool blur_cached = ref_xyb_cached && c->d_ref_blur && c->cap_blur;
-        mp->ref_mu[s] = blur_cached ? c->d_ref_blur + xyb_off(p, s) : nullptr;
-        mp->ref_s11[s] = blur_cached ? c->d_ref_blur + c->cap_blur + xyb_off(p, s) : nullptr;
+        mp->ref_s11[s] = blur_cached ? c->d_ref_blur + xyb_off(p, s) : nullptr;
         mp->part[s] = c->d_partials + poff;
         fa->part[s] = mp->part[s];
         fa->nblocks[s] = nb;
@@ -363,7 +362,7 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
     int blocks = 0;
     build_plans(c, p, d_ref, d_dist, ref_pyramid_ready && c->d_xyb_ref != nullptr, &mp, &fa, &blocks);
     if (blocks > 0) {
-        if (mp.ref_mu[0])  // reference XYB and blur planes cached: the search's per-pass kernel
+        if (mp.ref_s11[0])  // reference XYB and blur(ref*ref) cached: the search's per-pass kernel
             hipLaunchKernelGGL(k_march_refblur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
         else
             hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
@@ -592,14 +591,14 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
                                sc == 0, p.w[sc], p.h[sc], c->d_xyb_ref + xyb_off(p, sc));
         }
     }
-    // ... and the two blur planes that depend on the reference alone, blur(ref) and
-    // blur(ref*ref), at every scale: the per-pass kernel then blurs three planes instead of five
+    // ... and blur(ref*ref) at every scale, which depends on the reference alone: the per-pass
+    // kernel then blurs four planes instead of five (caching blur(ref) too was measured slower)
     if (c->d_xyb_ref && getenv("OAVIF_AMD_NO_REF_BLUR") == nullptr) {
         if (need_xyb > c->cap_blur) {
             (void)hipFree(c->d_ref_blur);
             c->d_ref_blur = nullptr;
             c->cap_blur = 0;
-            hipError_t e = hipMalloc(&c->d_ref_blur, 2 * need_xyb * sizeof(float));
+            hipError_t e = hipMalloc(&c->d_ref_blur, need_xyb * sizeof(float));
             if (e != hipSuccess) {  // not fatal either: the pass blurs all five planes
                 c->d_ref_blur = nullptr;
                 (void)hipGetLastError();

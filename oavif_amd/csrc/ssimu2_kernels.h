@@ -318,9 +318,8 @@ struct MarchPlan {
     const void* ref[kNumScales];   // scale 0: u8 interleaved; others: fp32 planes
     const void* dist[kNumScales];
     const float* ref_xyb[kNumScales];  // cached positive-XYB planes of the reference, or null
-    // blur(ref) and blur(ref*ref) planes [3][h][w] of the scale: read by MARCH_REFBLUR (cached
-    // once per search), written by MARCH_EMIT
-    float* ref_mu[kNumScales];
+    // blur(ref*ref) planes [3][h][w] of the scale: read by MARCH_REFBLUR (cached once per
+    // search), written by MARCH_EMIT
     float* ref_s11[kNumScales];
     double* part[kNumScales];      // [18][nblocks] partial sums of the scale
 };
@@ -328,11 +327,13 @@ struct MarchPlan {
 // Kernel modes of the marching body (one __global__ entry each, so every mode has its own
 // register allocation and the pair-score kernel is untouched by the others):
 //   MARCH_PAIR     both frames blurred in flight (any pair; what `value` measures)
-//   MARCH_REFBLUR  the two blurs that depend on the reference alone -- mu1 = blur(ref) and
-//                  s11 = blur(ref*ref) -- come from planes cached once per search (tq.zig:37
-//                  passes the same e.rgb on every pass); the blur waves keep three planes instead
-//                  of five.  Same operations on the same operands, so the score's bits do not move.
-//   MARCH_EMIT     writes those two planes (run once by ssimu2_set_reference)
+//   MARCH_REFBLUR  s11 = blur(ref*ref), which depends on the reference alone, comes from planes
+//                  cached once per search (tq.zig:37 passes the same e.rgb on every pass); the blur
+//                  waves keep four planes instead of five.  Same operations on the same operands,
+//                  so the score's bits do not move.  mu1 = blur(ref) depends on the reference
+//                  alone too, but caching it as well makes the kernel HBM-bound and slower
+//                  (measured): one cached plane is the balance point.
+//   MARCH_EMIT     writes that plane (run once by ssimu2_set_reference)
 enum { MARCH_PAIR = 0, MARCH_REFBLUR = 1, MARCH_EMIT = 2 };
 
 // Per-lane cursor of a blur wave over the cached / emitted reference blur planes of its channel:
@@ -343,12 +344,11 @@ enum { MARCH_PAIR = 0, MARCH_REFBLUR = 1, MARCH_EMIT = 2 };
 #define RB_AHEAD 4
 #endif
 struct MarchRefBlur {
-    float* mu;
     float* s11;
     int pitch;       // elements per row
     int rows_left;   // rows of this segment not loaded yet
     bool active;     // lane owns an output column (lanes >= MHALF of a blur wave only shadow lane 0)
-    float pmu[9], ps11[9];  // slot = phase of the consuming step; RB_AHEAD of them are live
+    float ps11[9];  // slot = phase of the consuming step; RB_AHEAD of them are live
 };
 
 // Raw values of one staged pixel of one frame of an input row (u8 codes or fp32 bits).
@@ -490,10 +490,8 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&
 #define H9P(a, b)                                                                              \
     fir9(a[4] * b[4], fmaf(a[3], b[3], a[5] * b[5]), fmaf(a[2], b[2], a[6] * b[6]),            \
          fmaf(a[1], b[1], a[7] * b[7]), fmaf(a[0], b[0], a[8] * b[8]), w0, w1, w2, w3, w4)
-    if (MODE != MARCH_REFBLUR) {
-        win[0][P] = H9(cur.x);
-        win[2][P] = H9P(cur.x, cur.x);
-    }
+    win[0][P] = H9(cur.x);
+    if (MODE != MARCH_REFBLUR) win[2][P] = H9P(cur.x, cur.x);
     if (MODE != MARCH_EMIT) {
         win[1][P] = H9(cur.y);
         win[3][P] = H9P(cur.y, cur.y);
@@ -502,15 +500,12 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&
 #undef H9
 #undef H9P
     const float r1 = cur.r1, r2 = cur.r2;
-    float c_mu = 0.f, c_s11 = 0.f;
+    float c_s11 = 0.f;
     if (MODE == MARCH_REFBLUR) {
-        // consume the values loaded RB_AHEAD steps ago, then load the row RB_AHEAD steps ahead
-        c_mu = rb.pmu[P];
+        // consume the value loaded RB_AHEAD steps ago, then load the row RB_AHEAD steps ahead
         c_s11 = rb.ps11[P];
         if (t >= 8 - RB_AHEAD && rb.rows_left > 0) {  // uniform: that output row exists
-            rb.pmu[(P + RB_AHEAD) % 9] = ok ? *rb.mu : 0.0f;
             rb.ps11[(P + RB_AHEAD) % 9] = ok ? *rb.s11 : 0.0f;
-            rb.mu += rb.pitch;
             rb.s11 += rb.pitch;
             --rb.rows_left;
         }
@@ -526,23 +521,19 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&
         float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            if (MODE == MARCH_REFBLUR && (k == 0 || k == 2)) continue;
-            if (MODE == MARCH_EMIT && !(k == 0 || k == 2)) continue;
+            if (MODE == MARCH_REFBLUR && k == 2) continue;
+            if (MODE == MARCH_EMIT && k != 2) continue;
             const float* q = win[k];
             v[k] = fir9(q[(P + 5) % 9], q[(P + 4) % 9] + q[(P + 6) % 9],
                         q[(P + 3) % 9] + q[(P + 7) % 9], q[(P + 2) % 9] + q[(P + 8) % 9],
                         q[(P + 1) % 9] + q[P], w0, w1, w2, w3, w4);
         }
-        if (MODE == MARCH_EMIT) {  // the reference's two blur planes, one row per step
-            if (ok && rb.active) {
-                *rb.mu = v[0];
-                *rb.s11 = v[2];
-            }
-            rb.mu += rb.pitch;
+        if (MODE == MARCH_EMIT) {  // the reference's blur(ref*ref) plane, one row per step
+            if (ok && rb.active) *rb.s11 = v[2];
             rb.s11 += rb.pitch;
             return;
         }
-        const float mu1 = MODE == MARCH_REFBLUR ? c_mu : v[0], mu2 = v[1];
+        const float mu1 = v[0], mu2 = v[1];
         const float s11 = MODE == MARCH_REFBLUR ? c_s11 : v[2], s22 = v[3], s12 = v[4];
         const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
         const float dm = mu1 - mu2;
@@ -618,12 +609,11 @@ __device__ __forceinline__ void march_body(const MarchPlan& plan) {
     rb.rows_left = rows_out;
     rb.active = hv_active;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) rb.pmu[k] = rb.ps11[k] = 0.f;
+    for (int k = 0; k < 9; ++k) rb.ps11[k] = 0.f;
     {
         // this lane's pixel in output row y0 of its channel's planes (column clamped: lanes
         // outside the image never dereference it)
         const size_t at = ((size_t)max(ch, 0) * h + y0) * (size_t)w + (size_t)min(x0 + o, w - 1);
-        rb.mu = MODE == MARCH_PAIR ? nullptr : plan.ref_mu[sc] + at;
         rb.s11 = MODE == MARCH_PAIR ? nullptr : plan.ref_s11[sc] + at;
     }
 
@@ -736,12 +726,12 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march(MarchPlan plan) {
     march_body<MARCH_PAIR>(plan);
 }
 
-// the per-pass kernel of a search: reference XYB and reference blur planes cached
+// the per-pass kernel of a search: reference XYB and blur(ref*ref) planes cached
 __global__ __launch_bounds__(MARCH_THREADS, 6) void k_march_refblur(MarchPlan plan) {
     march_body<MARCH_REFBLUR>(plan);
 }
 
-// once per search: blur(ref) and blur(ref*ref) of every scale into plan.ref_mu / plan.ref_s11
+// once per search: blur(ref*ref) of every scale into plan.ref_s11
 __global__ __launch_bounds__(MARCH_THREADS, 6) void k_ref_blur(MarchPlan plan) {
     march_body<MARCH_EMIT>(plan);
 }
