@@ -281,18 +281,26 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
 //   waves 0-1 (converters): lane = one staged column (MW + 8 halo = 128), both frames.  Each
 //     step they convert one input row (sRGB LUT at scale 0 -> opsin -> cbrt -> positive XYB)
 //     into an LDS ring of raw rows, one barrier group ahead of the blur waves; their global
-//     loads run one more group ahead, so HBM latency is off the critical path.
+//     loads run one more group ahead, so HBM latency is off the critical path.  At scale 0 a
+//     lane fetches its pixel with ONE dword load (the three bytes of the pixel plus one of the
+//     next), the wave's loads covering a contiguous 193-byte run of the row.
 //   waves 2-7 (blur + maps): two waves per XYB channel, lane = one output column.  Each step
-//     a lane reads its 9-wide window of x (ref) and y (dist) from the ring, forms the
+//     a lane reads its 9-wide window of (x, y) = (ref, dist) pairs from the ring, forms the
 //     products, does the horizontal 9-tap of the five planes {x, y, xx, yy, xy} in
 //     registers and pushes the results into a 9-row register window, from which the
 //     vertical 9-tap and the SSIM / edge-difference maps of the row four steps back are
 //     evaluated and accumulated.  The row loop is unrolled nine times so the window is
 //     addressed with compile-time indices (no register moves).
+//     LDS latency is taken off the critical path without extra registers: the five inner
+//     window pairs of the NEXT row are requested right after the horizontal pass of this row
+//     (when the tap registers are dead) and land under the vertical pass and the maps; the
+//     four outer pairs are requested at the top of the step and land under the partial sums
+//     of the inner ones.
 // One output pixel per lane keeps the window at 45 registers, and the two roles run separate
 // loops (own register allocation): <= 80 VGPRs, 3 workgroups = 24 waves per CU.  A lone wave
 // issues a VALU op only every ~4 cycles, so occupancy is what fills the SIMDs.
-// The workgroup synchronises once per GROUP rows.
+// The workgroup synchronises once per GROUP rows; in the blur waves the barrier sits between
+// the horizontal pass of the group's last row and the prefetch for the next group's first.
 // HBM traffic: each input pixel is read once per strip (+8/MW horizontal, +8/seg vertical
 // halo); only 18 partial sums per workgroup are written.
 // Scales are laid out largest first in the grid, so the short workgroups of the small scales
@@ -302,14 +310,17 @@ constexpr int MW = 120;        // output columns per strip
 constexpr int MRW = MW + 8;    // staged columns (4 px halo each side) = 128 = 2 waves per frame
 constexpr int MHALF = MW / 2;  // output columns per blur wave (lanes 0..59 active)
 constexpr int RING = 16;       // raw-row ring depth (power of two >= 13: rows t-4 .. t+8)
-#ifdef EXP_AHEAD
-constexpr int AHEAD = EXP_AHEAD;
-#else
 constexpr int AHEAD = 3;       // rows the converters run ahead of the blur waves (1 group)
-#endif
 constexpr int GROUP = 3;       // rows per barrier interval (divides the 9-phase unroll)
 constexpr int MARCH_THREADS = 512;
 constexpr int CONV_WAVES = 2;  // each converter lane handles one staged column of BOTH frames
+
+// One ring element: the positive-XYB value of one channel of one staged pixel in both frames,
+// .x = reference, .y = distorted.  Keeping the pair together makes every tap of the blur
+// waves one naturally aligned ds_read_b64 (256 B/clk/CU; the planar layout needed
+// ds_read2_b32, 128 B/clk/CU) and every converter store one ds_write_b64.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int RING_ROW = 3 * MRW;  // f2 elements per ring row: [channel][column]
 
 struct MarchPlan {
     int nscales;
@@ -340,9 +351,7 @@ enum { MARCH_PAIR = 0, MARCH_REFBLUR = 1, MARCH_EMIT = 2 };
 // the pixel of this lane's column in the next output row, plus a prefetch queue (the values are
 // loaded RB_AHEAD steps before the step that consumes them; HBM latency under load is several
 // row steps).
-#ifndef RB_AHEAD
-#define RB_AHEAD 4
-#endif
+constexpr int RB_AHEAD = 4;
 struct MarchRefBlur {
     float* s11;
     int pitch;       // elements per row
@@ -351,81 +360,177 @@ struct MarchRefBlur {
     float ps11[9];  // slot = phase of the consuming step; RB_AHEAD of them are live
 };
 
-// Raw values of one staged pixel of one frame of an input row (u8 codes or fp32 bits).
-struct MarchRaw {
-    uint32_t v[3];
-    bool ok;
-};
-
-// Per-lane read cursor over one frame: address of this lane's (column-clamped) pixel in the
-// next row to load; advanced by one row pitch per load, so no per-row 64-bit address math.
-struct MarchSrc {
-    const uint8_t* p;  // u8: interleaved RGB; otherwise fp32 planes
-    size_t plane;      // plane stride in elements (fp32 sources)
-    int pitch;         // bytes per row
-    bool u8;
-};
-
-__device__ __forceinline__ MarchSrc march_src(const void* base, bool u8, int w, int h, int gx,
-                                              int first_row) {
-    MarchSrc s;
-    const int gxc = min(max(gx, 0), w - 1);  // clamped: the value is discarded when gx is outside
-    s.u8 = u8;
-    s.plane = (size_t)w * h;
-    s.pitch = u8 ? w * 3 : w * 4;
-    s.p = (const uint8_t*)base + (ptrdiff_t)first_row * s.pitch + (size_t)gxc * (u8 ? 3 : 4);
-    return s;
+// ---- converter waves ------------------------------------------------------------------------------
+// opsin mix and the rest of linear_to_xyb_pos as two halves (same operations in the same order),
+// so that the sRGB LUT reads of the next row can be issued between them.
+__device__ __forceinline__ void opsin_mix(float r, float g, float b, float (&lms)[3]) {
+    lms[0] = fmaf(kM00, r, fmaf(kM01, g, fmaf(kM02, b, kOpsinBias)));
+    lms[1] = fmaf(kM10, r, fmaf(kM11, g, fmaf(kM12, b, kOpsinBias)));
+    lms[2] = fmaf(kM20, r, fmaf(kM21, g, fmaf(kM22, b, kOpsinBias)));
+}
+__device__ __forceinline__ void mixed_to_xyb_pos(const float (&lms)[3], float (&v)[3]) {
+    const float cb = c_k.cbrt_bias;
+    const float l = cbrt_repro_pos(lms[0]) - cb;
+    const float m = cbrt_repro_pos(lms[1]) - cb;
+    const float s = cbrt_repro_pos(lms[2]) - cb;
+    const float x = 0.5f * (l - m), y = 0.5f * (l + m);
+    v[2] = (s - y) + 0.55f;
+    v[0] = fmaf(x, 14.0f, 0.42f);
+    v[1] = y + 0.01f;
 }
 
-// Issue the global loads of the cursor's row and advance it.  `row_ok` (the row is inside the
-// image) is uniform over the workgroup; rows outside are never dereferenced.
-__device__ __forceinline__ void march_load(MarchRaw& raw, MarchSrc& s, bool row_ok, bool col_ok) {
-    raw.ok = row_ok && col_ok;
-    if (row_ok) {
-        if (s.u8) {
-            raw.v[0] = s.p[0];
-            raw.v[1] = s.p[1];
-            raw.v[2] = s.p[2];
+// Per-lane read cursor of a converter lane over one frame: address of this lane's
+// (column-clamped) pixel in the next row to load, advanced by one row pitch per load.
+//   u8 frames (scale 0): ONE unaligned dword load per pixel -- R | G << 8 | B << 16 | the next
+//     pixel's R << 24 -- so a wave's loads cover one contiguous 193-byte run of the row.  The
+//     lane of the image's last column reads one byte earlier and shifts (`shift` = 8), so no
+//     load ever reaches behind the frame's last byte.
+//   fp32 planes (scales >= 1, cached reference XYB): three dword loads, `plane` elements apart.
+struct MarchCursor {
+    const uint8_t* p;
+    size_t plane;
+    int pitch;       // bytes per row
+    uint32_t shift;  // u8 only
+};
+
+template <bool U8>
+__device__ __forceinline__ MarchCursor march_cursor(const void* base, int w, int h, int gxc, int first_row) {
+    MarchCursor c;
+    c.plane = (size_t)w * h;
+    c.pitch = U8 ? w * 3 : w * 4;
+    const bool last_col = U8 && gxc == w - 1;
+    c.shift = last_col ? 8u : 0u;
+    c.p = (const uint8_t*)base + (ptrdiff_t)first_row * c.pitch + (ptrdiff_t)gxc * (U8 ? 3 : 4) - (last_col ? 1 : 0);
+    return c;
+}
+
+template <bool U8>
+__device__ __forceinline__ void march_load(uint32_t (&raw)[3], MarchCursor& c, bool row_ok) {
+    if (row_ok) {  // uniform; rows outside the image are never dereferenced
+        if (U8) {
+            uint32_t d;
+            __builtin_memcpy(&d, c.p, 4);
+            raw[0] = d;
         } else {
-            const uint32_t* q = (const uint32_t*)s.p;
-            raw.v[0] = q[0];
-            raw.v[1] = q[s.plane];
-            raw.v[2] = q[2 * s.plane];
+            const uint32_t* q = (const uint32_t*)c.p;
+            raw[0] = q[0];
+            raw[1] = q[c.plane];
+            raw[2] = q[2 * c.plane];
         }
-    } else {
-        raw.v[0] = raw.v[1] = raw.v[2] = 0;
     }
-    s.p += s.pitch;
+    c.p += c.pitch;
 }
 
-// Convert the loaded pixel to positive XYB and store it into ring slot `slot` of frame k
-// (zeros outside the image: the blur is zero padded).
-__device__ __forceinline__ void march_convert(float (*ring)[3][2][MRW], const float* lut, bool u8,
-                                              const MarchRaw& raw, int slot, int k, int col) {
-    float rr, gg, bb, v[3];
-    if (u8) {
-        rr = lut[raw.v[0]];
-        gg = lut[raw.v[1]];
-        bb = lut[raw.v[2]];
-    } else {
-        rr = __uint_as_float(raw.v[0]);
-        gg = __uint_as_float(raw.v[1]);
-        bb = __uint_as_float(raw.v[2]);
-    }
-#ifdef ABL_NOCONV
-    v[0] = rr; v[1] = gg; v[2] = bb;
-#else
-    linear_to_xyb_pos(rr, gg, bb, v[0], v[1], v[2]);
-#endif
-#pragma unroll
-    for (int c = 0; c < 3; ++c) ring[slot][c][k][col] = raw.ok ? v[c] : 0.0f;
+__device__ __forceinline__ void march_lut(const float* lut, uint32_t d, uint32_t shift, float (&lin)[3]) {
+    d >>= shift;
+    lin[0] = lut[d & 255u];
+    lin[1] = lut[(d >> 8) & 255u];
+    lin[2] = lut[(d >> 16) & 255u];
 }
 
-// Cached reference: the loaded values already are positive XYB (k_ref_xyb); store them.
-__device__ __forceinline__ void march_store_xyb(float (*ring)[3][2][MRW], const MarchRaw& raw, int slot,
-                                                int k, int col) {
+// The converter role of one workgroup: rows 0 .. steps-1 of the segment into the ring, GROUP
+// rows per barrier interval, global loads GROUP rows ahead of their use.
+//   U8    the frames are 8-bit sRGB (scale 0); otherwise fp32 linear-light planes
+//   MODE  MARCH_PAIR: both frames converted.  MARCH_REFBLUR: frame 0 is the cached positive-XYB
+//         planes of the reference (no arithmetic).  MARCH_EMIT: the same, and frame 1 is not needed.
+// Per row and lane: [LUT values of this row, requested one row earlier] -> opsin mix of both
+// frames -> request the LUT values of the next row -> cube roots, XYB, one ds_write_b64 per
+// channel.  The LUT reads therefore land under ~100 arithmetic instructions.
+template <bool U8, int MODE>
+__device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const float* lut,
+                                                   const MarchPlan& plan, int sc, int w, int h, int x0,
+                                                   int y0, int steps, int ngroups, int col) {
+    constexpr bool CACHED = MODE != MARCH_PAIR;
+    constexpr bool TWO = MODE != MARCH_EMIT;
+    constexpr bool LUT0 = U8 && !CACHED;  // frame 0 goes through the sRGB LUT
+    const int gx = x0 - RAD + col;
+    const bool col_ok = gx >= 0 && gx < w;
+    const bool all_cols = x0 - RAD >= 0 && x0 - RAD + MRW <= w;  // uniform: no lane outside the image
+    const int gxc = min(max(gx, 0), w - 1);  // clamped: the value is discarded when gx is outside
+    MarchCursor c0 = CACHED ? march_cursor<false>(plan.ref_xyb[sc], w, h, gxc, y0 - RAD)
+                            : march_cursor<U8>(plan.ref[sc], w, h, gxc, y0 - RAD);
+    MarchCursor c1 = march_cursor<U8>(plan.dist[sc], w, h, gxc, y0 - RAD);
+    int load_row = y0 - RAD;  // image row the cursors point at
+    // raw[f][j]: loaded, not yet converted row of frame f; slot j is refilled every GROUP rows, so
+    // the GROUP-deep prefetch queue rotates with the unrolled group (no register moves)
+    uint32_t raw0[GROUP][3], raw1[GROUP][3];
+    bool rok[GROUP];
+    float lin0[3] = {0.f, 0.f, 0.f}, lin1[3] = {0.f, 0.f, 0.f};  // LUT values of the next row to convert
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ring[slot][c][k][col] = raw.ok ? __uint_as_float(raw.v[c]) : 0.0f;
+    for (int j = 0; j < GROUP; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw0[j][k] = raw1[j][k] = 0;
+    // A row outside the image (only in the halo of the image's first and last segments) is not
+    // loaded -- its queue slot keeps the previous, valid row -- and is converted like any other;
+    // its values are then replaced by the blur's zero padding together with the columns outside
+    // the image.  So the row body is straight-line code: no per-row branch around the arithmetic.
+#define MARCH_LOAD(J)                                                \
+    {                                                                \
+        rok[J] = load_row >= 0 && load_row < h;                      \
+        if (CACHED) march_load<false>(raw0[J], c0, rok[J]);          \
+        else march_load<U8>(raw0[J], c0, rok[J]);                    \
+        if (TWO) march_load<U8>(raw1[J], c1, rok[J]);                \
+        ++load_row;                                                  \
+    }
+#define MARCH_LUT(J)                                                             \
+    if (U8) {                                                                    \
+        if (LUT0) march_lut(lut, raw0[J][0], c0.shift, lin0);                    \
+        if (TWO) march_lut(lut, raw1[J][0], c1.shift, lin1);                     \
+    }
+#define MARCH_PUT(J, SLOT)                                                                     \
+    {                                                                                          \
+        float a_[3] = {0.f, 0.f, 0.f}, b_[3] = {0.f, 0.f, 0.f};                                \
+        float m0_[3], m1_[3];                                                                  \
+        if (!CACHED) {                                                                         \
+            if (U8) opsin_mix(lin0[0], lin0[1], lin0[2], m0_);                                 \
+            else opsin_mix(__uint_as_float(raw0[J][0]), __uint_as_float(raw0[J][1]),           \
+                           __uint_as_float(raw0[J][2]), m0_);                                  \
+        }                                                                                      \
+        if (TWO) {                                                                             \
+            if (U8) opsin_mix(lin1[0], lin1[1], lin1[2], m1_);                                 \
+            else opsin_mix(__uint_as_float(raw1[J][0]), __uint_as_float(raw1[J][1]),           \
+                           __uint_as_float(raw1[J][2]), m1_);                                  \
+        }                                                                                      \
+        if (U8) {                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            MARCH_LUT((J + 1) % GROUP)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+        if (CACHED) {                                                                          \
+            _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) a_[c_] = __uint_as_float(raw0[J][c_]); \
+        } else {                                                                               \
+            mixed_to_xyb_pos(m0_, a_);                                                         \
+        }                                                                                      \
+        if (TWO) mixed_to_xyb_pos(m1_, b_);                                                    \
+        if (!(all_cols && rok[J])) { /* uniform */                                             \
+            const bool keep_ = col_ok && rok[J];                                               \
+            _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                                 \
+                a_[c_] = keep_ ? a_[c_] : 0.0f;                                                \
+                b_[c_] = keep_ ? b_[c_] : 0.0f;                                                \
+            }                                                                                  \
+        }                                                                                      \
+        _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) ring[SLOT][c_][col] = f2{a_[c_], b_[c_]}; \
+    }
+#pragma unroll
+    for (int j = 0; j < GROUP; ++j) MARCH_LOAD(j)  // rows 0 .. GROUP-1
+    MARCH_LUT(0)
+    // iteration g produces ring rows 3g .. 3g+2 (the blur waves consume them in their iteration
+    // g, one barrier later) and loads rows 3g+3 .. 3g+5; the last iteration only joins the barrier
+#pragma unroll 1
+    for (int g = 0; g <= ngroups; ++g) {
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            const int r = g * GROUP + j;  // ring row to produce (uniform)
+            if (r < steps) {
+                MARCH_PUT(j, r & (RING - 1))
+                MARCH_LOAD(j)  // row r + GROUP
+            }
+        }
+        __syncthreads();
+    }
+#undef MARCH_LOAD
+#undef MARCH_LUT
+#undef MARCH_PUT
 }
 
 // Positive-XYB planes of one frame at one scale (run once per search for the reference, whose
@@ -454,52 +559,60 @@ __global__ __launch_bounds__(256) void k_ref_xyb(const void* __restrict__ in, bo
     out[2 * n + i] = B;
 }
 
-// LDS reads of one blur-wave step: the 9-wide x / y windows of ring row t and the centre pixel
-// of the output row (t - 4).  Issued one step ahead of their use (see march_hv_step).
-struct MarchTaps {
-    float x[9], y[9], r1, r2;
+// One (ref, dist) pair as it sits in the ring, fetched with one ds_read_b64 and split into its
+// two 32-bit halves (sub-registers: no instruction).  Kept as a 64-bit integer rather than a
+// float vector so that the compiler does not pair up the x / y arithmetic into v_pk_*_f32,
+// which ties values to even-aligned register pairs the 80-VGPR budget has no room for.
+struct MarchPair {
+    unsigned long long u;
+    __device__ __forceinline__ float x() const { return __uint_as_float((uint32_t)u); }
+    __device__ __forceinline__ float y() const { return __uint_as_float((uint32_t)(u >> 32)); }
 };
+// volatile: one ds_read_b64 per tap.  The compiler would otherwise fuse neighbouring taps into
+// ds_read2_b64, which the LDS serves at half the rate of two ds_read_b64 (measured: +3 %).
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
 
-__device__ __forceinline__ void march_hv_fetch(MarchTaps& m, float (*ring)[3][2][MRW], int t, int ch,
-                                               int o) {
-    const int slot = t & (RING - 1);
-    const float* px = &ring[slot][ch][0][o];  // staged columns o .. o+8, centre o+4
-    const float* py = &ring[slot][ch][1][o];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        m.x[q] = px[q];
-        m.y[q] = py[q];
-    }
-    const int cslot = (t - 4) & (RING - 1);
-    m.r1 = ring[cslot][ch][0][o + RAD];
-    m.r2 = ring[cslot][ch][1][o + RAD];
+__device__ __forceinline__ const lds_vu64* march_row(const lds_vu64* rp, int t) {
+    return rp + (t & (RING - 1)) * RING_ROW;
 }
 
+// Horizontal pass of ring row t into window slot P: the lane's 9-wide window of (x, y) pairs
+// (staged columns o .. o+8, centre o+4), nine ds_read_b64.
+// plain planes: pair sums of the taps; product planes: the products are formed inside the
+// pair sums as fma(a-, b-, a+ * b+) -- one rounding and one operation fewer than two
+// products and an add (arithmetic contract, mirrored by the CPU checker)
 template <int P, int MODE>
-__device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&win)[5][9],
-                                              float (&acc)[6], int t, int ch, int o, bool ok,
-                                              float w0, float w1, float w2, float w3, float w4,
-                                              MarchRefBlur& rb) {
-    MarchTaps cur;
-    march_hv_fetch(cur, ring, t, ch, o);
-    // plain planes: pair sums of the taps; product planes: the products are formed inside the
-    // pair sums as fma(a-, b-, a+ * b+) -- one rounding and one operation fewer than two
-    // products and an add (arithmetic contract, mirrored by the CPU checker)
-#define H9(v) \
-    fir9(v[4], v[3] + v[5], v[2] + v[6], v[1] + v[7], v[0] + v[8], w0, w1, w2, w3, w4)
-#define H9P(a, b)                                                                              \
-    fir9(a[4] * b[4], fmaf(a[3], b[3], a[5] * b[5]), fmaf(a[2], b[2], a[6] * b[6]),            \
-         fmaf(a[1], b[1], a[7] * b[7]), fmaf(a[0], b[0], a[8] * b[8]), w0, w1, w2, w3, w4)
-    win[0][P] = H9(cur.x);
-    if (MODE != MARCH_REFBLUR) win[2][P] = H9P(cur.x, cur.x);
+__device__ __forceinline__ void march_h(const lds_vu64* rp, float (&win)[5][9], int t, float w0,
+                                        float w1, float w2, float w3, float w4) {
+    const lds_vu64* row = march_row(rp, t);
+    MarchPair v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) v[q].u = row[q];
+#define H9(f) \
+    fir9(v[4].f(), v[3].f() + v[5].f(), v[2].f() + v[6].f(), v[1].f() + v[7].f(), v[0].f() + v[8].f(), \
+         w0, w1, w2, w3, w4)
+#define H9P(a, b)                                                                                      \
+    fir9(v[4].a() * v[4].b(), fmaf(v[3].a(), v[3].b(), v[5].a() * v[5].b()),                           \
+         fmaf(v[2].a(), v[2].b(), v[6].a() * v[6].b()), fmaf(v[1].a(), v[1].b(), v[7].a() * v[7].b()), \
+         fmaf(v[0].a(), v[0].b(), v[8].a() * v[8].b()), w0, w1, w2, w3, w4)
+    win[0][P] = H9(x);
+    if (MODE != MARCH_REFBLUR) win[2][P] = H9P(x, x);
     if (MODE != MARCH_EMIT) {
-        win[1][P] = H9(cur.y);
-        win[3][P] = H9P(cur.y, cur.y);
-        win[4][P] = H9P(cur.x, cur.y);
+        win[1][P] = H9(y);
+        win[3][P] = H9P(y, y);
+        win[4][P] = H9P(x, y);
     }
 #undef H9
 #undef H9P
-    const float r1 = cur.r1, r2 = cur.r2;
+}
+
+// Second half of step t: vertical pass and maps of output row t - 4 (window slot of row t - j
+// is (P - j) mod 9).  `edge`: the strip reaches past the image's right edge, so lanes whose
+// column is outside (`!ok`) must not contribute (uniform; interior strips skip the selects).
+template <int P, int MODE>
+__device__ __forceinline__ void march_v(const lds_vu64* rp, float (&win)[5][9], float (&acc)[6], int t,
+                                        bool ok, bool edge, float w0, float w1, float w2, float w3,
+                                        float w4, MarchRefBlur& rb) {
     float c_s11 = 0.f;
     if (MODE == MARCH_REFBLUR) {
         // consume the value loaded RB_AHEAD steps ago, then load the row RB_AHEAD steps ahead
@@ -510,65 +623,54 @@ __device__ __forceinline__ void march_hv_step(float (*ring)[3][2][MRW], float (&
             --rb.rows_left;
         }
     }
-#ifdef ABL_NOVMAPS
-    if (t >= 8) { acc[0] += win[0][(P + 5) % 9] + win[1][P] + win[2][P] + win[3][P] + win[4][P]; }
-    if (t < 0)
-#else
-    if (t >= 8)
-#endif
-    {  // window full (uniform across the workgroup)
-        // vertical 9-tap for the row four steps back: row t-j sits in window slot (P-j) mod 9
-        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t < 8) return;  // window not full yet (uniform across the workgroup)
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (MODE == MARCH_REFBLUR && k == 2) continue;
-            if (MODE == MARCH_EMIT && k != 2) continue;
-            const float* q = win[k];
-            v[k] = fir9(q[(P + 5) % 9], q[(P + 4) % 9] + q[(P + 6) % 9],
-                        q[(P + 3) % 9] + q[(P + 7) % 9], q[(P + 2) % 9] + q[(P + 8) % 9],
-                        q[(P + 1) % 9] + q[P], w0, w1, w2, w3, w4);
-        }
-        if (MODE == MARCH_EMIT) {  // the reference's blur(ref*ref) plane, one row per step
-            if (ok && rb.active) *rb.s11 = v[2];
-            rb.s11 += rb.pitch;
-            return;
-        }
-        const float mu1 = v[0], mu2 = v[1];
-        const float s11 = MODE == MARCH_REFBLUR ? c_s11 : v[2], s22 = v[3], s12 = v[4];
-        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
-        const float dm = mu1 - mu2;
-        const float num_m = fmaf(-dm, dm, 1.0f);
-        const float num_s = fmaf(2.0f, s12 - mu12, kC2);
-        const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
-        float d = 1.0f - div_rn(num_m * num_s, denom_s);
-        d = fmaxf(d, 0.0f);
-        const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
-        float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
-        d = ok ? d : 0.0f;                      // column inside the image?
-        e = ok ? e : 0.0f;
-        const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
-        const float d2 = d * d, a2 = art * art, t2 = det * det;
-        acc[0] += d;
-        acc[1] += d2 * d2;
-        acc[2] += art;
-        acc[3] += a2 * a2;
-        acc[4] += det;
-        acc[5] += t2 * t2;
+    for (int k = 0; k < 5; ++k) {
+        if (MODE == MARCH_REFBLUR && k == 2) continue;
+        if (MODE == MARCH_EMIT && k != 2) continue;
+        const float* q = win[k];
+        v[k] = fir9(q[(P + 5) % 9], q[(P + 4) % 9] + q[(P + 6) % 9],
+                    q[(P + 3) % 9] + q[(P + 7) % 9], q[(P + 2) % 9] + q[(P + 8) % 9],
+                    q[(P + 1) % 9] + q[P], w0, w1, w2, w3, w4);
     }
+    if (MODE == MARCH_EMIT) {  // the reference's blur(ref*ref) plane, one row per step
+        if (ok && rb.active) *rb.s11 = v[2];
+        rb.s11 += rb.pitch;
+        return;
+    }
+    MarchPair ctr;
+    ctr.u = march_row(rp, t - 4)[RAD];  // centre pixel of the output row
+    const float r1 = ctr.x(), r2 = ctr.y();
+    const float mu1 = v[0], mu2 = v[1];
+    const float s11 = MODE == MARCH_REFBLUR ? c_s11 : v[2], s22 = v[3], s12 = v[4];
+    const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+    const float dm = mu1 - mu2;
+    const float num_m = fmaf(-dm, dm, 1.0f);
+    const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+    const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+    float d = 1.0f - div_rn(num_m * num_s, denom_s);
+    d = fmaxf(d, 0.0f);
+    const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+    float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
+    if (edge) {
+        d = ok ? d : 0.0f;  // column inside the image?
+        e = ok ? e : 0.0f;
+    }
+    const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
+    const float d2 = d * d, a2 = art * art, t2 = det * det;
+    acc[0] += d;
+    acc[1] += d2 * d2;
+    acc[2] += art;
+    acc[3] += a2 * a2;
+    acc[4] += det;
+    acc[5] += t2 * t2;
 }
-
-// Timing-only ablation switches (scripts/ablate.sh); never defined in the product build.
-#ifdef ABL_NOBARRIER
-#define MARCH_BARRIER() ((void)0)
-#else
-#define MARCH_BARRIER() __syncthreads()
-#endif
 
 template <int MODE>
 __device__ __forceinline__ void march_body(const MarchPlan& plan) {
-    // [row slot][channel][frame][column]: the x (ref) and y (dist) windows of a channel are 512 B
-    // apart, inside the 8-bit dword offset of one ds_read2 base register
-    __shared__ __attribute__((aligned(16))) float s_ring[RING][3][2][MRW];
+    // [row slot][channel][column] of (ref, dist) pairs
+    __shared__ __attribute__((aligned(16))) f2 s_ring[RING][3][MRW];
     __shared__ float s_lut[256];
     __shared__ double s_part[6][6];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -618,75 +720,30 @@ __device__ __forceinline__ void march_body(const MarchPlan& plan) {
     }
 
     // Input row j (= image row y0-4+j) lives in ring slot j & (RING-1).  While the blur waves
-    // consume rows 3I..3I+2 the converters fill rows 3I+AHEAD..3I+AHEAD+2.  The two roles run separate loops with the same
-    // number of barriers (one per group of GROUP rows), so each gets its own register
-    // allocation instead of carrying the other role's state.
+    // consume rows 3I..3I+2 the converters fill rows 3I+AHEAD..3I+AHEAD+2.  The two roles run
+    // separate loops with the same number of barriers (one per group of GROUP rows), so each
+    // gets its own register allocation instead of carrying the other role's state.
     const int ngroups = (steps + GROUP - 1) / GROUP;
     if (is_conv) {
-        // The converter waves carry the heavier per-row stream on their SIMDs (~225 vs ~180
-        // instructions); a static issue-priority bump lets them keep pace (measured: -7 %).
-#ifndef EXP_CONV_PRIO
-#define EXP_CONV_PRIO 1
-#endif
-        __builtin_amdgcn_s_setprio(EXP_CONV_PRIO);
+        // The converter waves carry the heavier per-row stream on their SIMDs; a static
+        // issue-priority bump lets them keep pace (measured: -7 %).
+        __builtin_amdgcn_s_setprio(1);
         const int col = (wave << 6) + lane;  // staged column; this lane converts both frames
-        const int gx = x0 - RAD + col;
-        const bool col_ok = gx >= 0 && gx < w;
-        // reference frame: cached positive-XYB planes (fp32, no conversion) when available
-        const bool ref_cached = plan.ref_xyb[sc] != nullptr;
-        MarchSrc src0 = march_src(ref_cached ? (const void*)plan.ref_xyb[sc] : plan.ref[sc],
-                                  u8 && !ref_cached, w, h, gx, y0 - RAD);
-        MarchSrc src1 = march_src(plan.dist[sc], u8, w, h, gx, y0 - RAD);
-        int load_row = y0 - RAD;  // image row the cursors point at
-#define MARCH_LOAD2(Q0, Q1)                                          \
-    {                                                                \
-        const bool row_ok = load_row >= 0 && load_row < h;           \
-        march_load(Q0, src0, row_ok, col_ok);                        \
-        march_load(Q1, src1, row_ok, col_ok);                        \
-        ++load_row;                                                  \
-    }
-#define MARCH_PUT2(Q0, Q1, SLOT)                                            \
-    {                                                                       \
-        if (ref_cached) march_store_xyb(s_ring, Q0, SLOT, 0, col);          \
-        else march_convert(s_ring, s_lut, src0.u8, Q0, SLOT, 0, col);       \
-        march_convert(s_ring, s_lut, u8, Q1, SLOT, 1, col);                 \
-    }
-        // q[f][j]: loaded, not yet converted row of frame f; slot j is refilled every GROUP rows,
-        // so the GROUP-deep prefetch queue rotates with the unrolled group (no register moves)
-        MarchRaw q[2][GROUP];
-#pragma unroll
-        for (int j0 = 0; j0 < AHEAD; j0 += GROUP) {  // prologue: ring rows 0 .. AHEAD-1
-#pragma unroll
-            for (int j = 0; j < GROUP; ++j) MARCH_LOAD2(q[0][j], q[1][j])
-#pragma unroll
-            for (int j = 0; j < GROUP; ++j) MARCH_PUT2(q[0][j], q[1][j], j0 + j)
-        }
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) MARCH_LOAD2(q[0][j], q[1][j])  // rows AHEAD .. AHEAD+2
-        MARCH_BARRIER();
-#pragma unroll 1
-        for (int g = 0; g < ngroups; ++g) {
-#pragma unroll
-            for (int j = 0; j < GROUP; ++j) {
-                const int r = g * GROUP + j + AHEAD;  // ring row to produce (uniform)
-                if (r < steps) {
-                    MARCH_PUT2(q[0][j], q[1][j], r & (RING - 1))
-                    MARCH_LOAD2(q[0][j], q[1][j])  // row r + GROUP, consumed next iteration
-                }
-            }
-            MARCH_BARRIER();
-        }
-#undef MARCH_LOAD2
-#undef MARCH_PUT2
+        if (u8) march_convert_rows<true, MODE>(s_ring, s_lut, plan, sc, w, h, x0, y0, steps, ngroups, col);
+        else march_convert_rows<false, MODE>(s_ring, s_lut, plan, sc, w, h, x0, y0, steps, ngroups, col);
     } else {
         float win[5][9];
-        MARCH_BARRIER();
-#define MARCH_STEP(P)                                                                     \
-    {                                                                                     \
-        const int t = t0 + P;                                                             \
-        if (t < steps)                                                                    \
-            march_hv_step<P, MODE>(s_ring, win, acc, t, ch, o, ok, w0, w1, w2, w3, w4, rb); \
-        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) MARCH_BARRIER();         \
+        const lds_vu64* rp = (const lds_vu64*)&s_ring[0][ch][o];  // staged columns o .. o+8, centre o+4
+        const bool edge = x0 + MW > w;  // uniform: some lanes of this strip are outside the image
+        __syncthreads();
+        // step t: horizontal pass of ring row t; [barrier after the group's last row]; vertical
+        // pass + maps of output row t - 4
+#define MARCH_STEP(P)                                                                          \
+    {                                                                                          \
+        const int t = t0 + P;                                                                  \
+        if (t < steps) march_h<P, MODE>(rp, win, t, w0, w1, w2, w3, w4);                       \
+        if ((P % GROUP) == GROUP - 1 && t - (GROUP - 1) < steps) __syncthreads();              \
+        if (t < steps) march_v<P, MODE>(rp, win, acc, t, ok, edge, w0, w1, w2, w3, w4, rb);    \
     }
 #pragma unroll 1
         for (int t0 = 0; t0 < steps; t0 += 9) {

@@ -1,64 +1,117 @@
-// VALU issue-rate microbenchmark for gfx950: wave-instructions per cycle per SIMD for
-// v_fma_f32 / v_mul+v_add / v_pk_fma_f32 at 1..8 waves per SIMD.
+// VALU issue-rate microbenchmark for gfx950: ns per wave-instruction per SIMD for the
+// instruction kinds the marching kernel is made of, at 1..8 waves per SIMD.
+// Eight independent dependency chains per wave, 64 instructions per loop iteration.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
+enum { FMA, MULADD, PKFMA, FMAC_S, FMAMK, MULHI, RCP, CNDMASK, SDWA, LSHLADD64, NMODES };
+static const char* kNames[NMODES] = {"v_fma_f32", "v_mul/v_add", "v_pk_fma_f32", "v_fmac_f32 (sgpr)",
+                                     "v_fmamk_f32 (literal)", "v_mul_hi_u32", "v_rcp_f32",
+                                     "v_cndmask_b32 (sgpr mask)", "v_lshlrev_b32_sdwa", "v_lshl_add_u64"};
+
+#define REP8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
 template <int MODE>
 __global__ void k(float* out, int iters, float a, float b) {
-    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
-    float2_ p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
+    float x[8];
+    float2_ p[8];
+    unsigned long long q[8];
+    for (int i = 0; i < 8; ++i) {
+        x[i] = threadIdx.x + i + 1.0f;
+        p[i] = float2_{x[i], x[i] + 1.0f};
+        q[i] = threadIdx.x * 8 + i;
+    }
     float2_ pa = {a, a}, pb = {b, b};
+    const float sa = __builtin_amdgcn_readfirstlane(__float_as_int(a)) ? a : b;  // uniform
+    const unsigned long long mask = 0x5555555555555555ull;
     for (int i = 0; i < iters; ++i) {
-        if (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
-                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
-                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-            }
-        } else if (MODE == 1) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n"
-                             "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9\n"
-                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
-                             "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
-                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa), "v"(pb));
+        for (int r = 0; r < 8; ++r) {
+            if (MODE == FMA) {
+#define OP(j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));
+                REP8(OP)
+#undef OP
+            } else if (MODE == MULADD) {
+#define OP(j) if (j & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[j]) : "v"(b)); else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j]) : "v"(a));
+                REP8(OP)
+#undef OP
+            } else if (MODE == PKFMA) {
+#define OP(j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[j]) : "v"(pa), "v"(pb));
+                REP8(OP)
+#undef OP
+            } else if (MODE == FMAC_S) {
+#define OP(j) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[j]) : "s"(sa), "v"(b));
+                REP8(OP)
+#undef OP
+            } else if (MODE == FMAMK) {
+#define OP(j) asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %1" : "+v"(x[j]) : "v"(b));
+                REP8(OP)
+#undef OP
+            } else if (MODE == MULHI) {
+#define OP(j) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[j]) : "s"(0xAAAAAAABu));
+                REP8(OP)
+#undef OP
+            } else if (MODE == RCP) {
+#define OP(j) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[j]));
+                REP8(OP)
+#undef OP
+            } else if (MODE == CNDMASK) {
+#define OP(j) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(x[j]) : "s"(mask));
+                REP8(OP)
+#undef OP
+            } else if (MODE == SDWA) {
+#define OP(j) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(x[j]) : "v"(2));
+                REP8(OP)
+#undef OP
+            } else if (MODE == LSHLADD64) {
+#define OP(j) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[j]) : "s"(mask));
+                REP8(OP)
+#undef OP
             }
         }
     }
-    float s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += x[i] + p[i].x + p[i].y + (float)q[i];
     if (s == 12345.678f) out[0] = s;
 }
 
 template <int MODE>
-void run(const char* name, float* d) {
-    const int iters = 20000;
-    for (int wps = 1; wps <= 8; wps *= 2) {
+void run(float* d) {
+    const int iters = 8000;
+    for (int wps = 1; wps <= 8; wps = wps == 4 ? 6 : (wps == 6 ? 8 : wps * 2)) {
         // block = 256 threads = 4 waves = 1 wave per SIMD; wps blocks per CU
         int blocks = 256 * wps;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 0.999f, 0.001f);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 2000, 0.999f, 0.001f);
         hipEventRecord(e0);
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 0.999f, 0.001f);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
         double instr_per_wave = (double)iters * 64;
-        double ns_per_instr_per_simd = ms * 1e6 / (instr_per_wave * wps);
-        printf("%-14s waves/SIMD=%d  %.3f ms  -> %.3f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz)\n", name, wps, ms, ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4);
+        double ns = ms * 1e6 / (instr_per_wave * wps);
+        printf("%-26s waves/SIMD=%d  %.3f ms  -> %.3f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz)\n",
+               kNames[MODE], wps, ms, ns, ns * 2.4);
     }
 }
+
 int main() {
-    float* d; hipMalloc(&d, 1024);
-    run<0>("v_fma_f32", d);
-    run<1>("v_mul/v_add", d);
-    run<2>("v_pk_fma_f32", d);
+    float* d;
+    hipMalloc(&d, 1024);
+    run<FMA>(d);
+    run<MULADD>(d);
+    run<PKFMA>(d);
+    run<FMAC_S>(d);
+    run<FMAMK>(d);
+    run<MULHI>(d);
+    run<RCP>(d);
+    run<CNDMASK>(d);
+    run<SDWA>(d);
+    run<LSHLADD64>(d);
     return 0;
 }
