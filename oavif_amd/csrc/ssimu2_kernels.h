@@ -45,12 +45,14 @@ __constant__ DevConst c_k;
 
 // ---- device helpers ---------------------------------------------------------------------------
 
-// Cube root from IEEE mul/fma only: bit-trick seed for y = x^(-1/3), one third-order step
+// Cube root from IEEE mul/fma only (arguments are in [0, 2)): bit-trick seed for y = x^(-1/3), one third-order step
 // y (1 + e/3 + 2e^2/9 + 14e^3/81) with e = 1 - x y^3, c = x y^2, one residual-corrected Newton
 // step on c.  17 operations, max error 0.76 ulp.
 __device__ __forceinline__ float cbrt_repro(float x) {
     uint32_t i = __float_as_uint(x);
-    i = 0x54A21D2Au - i / 3u;
+    // i / 3 as one multiply-high: floor(i * 0x55555556 / 2^32) == i / 3 for every i < 2^31
+    // (checked exhaustively), and the bits of a float below 2.0 are below 2^30
+    i = 0x54A21D2Au - __umulhi(i, 0x55555556u);
     float y = __uint_as_float(i);
     float t = x * y;
     t = t * y;
@@ -90,7 +92,9 @@ __device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float& 
 // the published clamp to zero and cbrt_repro's x > 0 guard can never act and are left out.
 __device__ __forceinline__ float cbrt_repro_pos(float x) {
     uint32_t i = __float_as_uint(x);
-    i = 0x54A21D2Au - i / 3u;
+    // i / 3 as one multiply-high: floor(i * 0x55555556 / 2^32) == i / 3 for every i < 2^31
+    // (checked exhaustively), and the bits of a float below 2.0 are below 2^30
+    i = 0x54A21D2Au - __umulhi(i, 0x55555556u);
     float y = __uint_as_float(i);
     float t = x * y;
     t = t * y;
@@ -387,20 +391,22 @@ __device__ __forceinline__ void mixed_to_xyb_pos(const float (&lms)[3], float (&
 //     load ever reaches behind the frame's last byte.
 //   fp32 planes (scales >= 1, cached reference XYB): three dword loads, `plane` elements apart.
 struct MarchCursor {
-    const uint8_t* p;
-    size_t plane;
-    int pitch;       // bytes per row
-    uint32_t shift;  // u8 only
+    const uint8_t* row;  // uniform: first byte of the next row to load (advanced by the scalar unit)
+    uint32_t off;        // per lane: byte offset of this lane's pixel inside a row
+    size_t plane;        // bytes between planes (fp32 sources)
+    int pitch;           // bytes per row
+    uint32_t shift;      // u8 only
 };
 
 template <bool U8>
 __device__ __forceinline__ MarchCursor march_cursor(const void* base, int w, int h, int gxc, int first_row) {
     MarchCursor c;
-    c.plane = (size_t)w * h;
+    c.plane = (size_t)w * h * 4;
     c.pitch = U8 ? w * 3 : w * 4;
     const bool last_col = U8 && gxc == w - 1;
     c.shift = last_col ? 8u : 0u;
-    c.p = (const uint8_t*)base + (ptrdiff_t)first_row * c.pitch + (ptrdiff_t)gxc * (U8 ? 3 : 4) - (last_col ? 1 : 0);
+    c.row = (const uint8_t*)base + (ptrdiff_t)first_row * c.pitch;
+    c.off = (uint32_t)gxc * (U8 ? 3u : 4u) - (last_col ? 1u : 0u);
     return c;
 }
 
@@ -409,16 +415,15 @@ __device__ __forceinline__ void march_load(uint32_t (&raw)[3], MarchCursor& c, b
     if (row_ok) {  // uniform; rows outside the image are never dereferenced
         if (U8) {
             uint32_t d;
-            __builtin_memcpy(&d, c.p, 4);
+            __builtin_memcpy(&d, c.row + c.off, 4);
             raw[0] = d;
         } else {
-            const uint32_t* q = (const uint32_t*)c.p;
-            raw[0] = q[0];
-            raw[1] = q[c.plane];
-            raw[2] = q[2 * c.plane];
+            raw[0] = *(const uint32_t*)(c.row + c.off);
+            raw[1] = *(const uint32_t*)(c.row + c.plane + c.off);
+            raw[2] = *(const uint32_t*)(c.row + 2 * c.plane + c.off);
         }
     }
-    c.p += c.pitch;
+    c.row += c.pitch;
 }
 
 __device__ __forceinline__ void march_lut(const float* lut, uint32_t d, uint32_t shift, float (&lin)[3]) {
@@ -454,7 +459,6 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
     // raw[f][j]: loaded, not yet converted row of frame f; slot j is refilled every GROUP rows, so
     // the GROUP-deep prefetch queue rotates with the unrolled group (no register moves)
     uint32_t raw0[GROUP][3], raw1[GROUP][3];
-    bool rok[GROUP];
     float lin0[3] = {0.f, 0.f, 0.f}, lin1[3] = {0.f, 0.f, 0.f};  // LUT values of the next row to convert
 #pragma unroll
     for (int j = 0; j < GROUP; ++j)
@@ -464,21 +468,24 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
     // loaded -- its queue slot keeps the previous, valid row -- and is converted like any other;
     // its values are then replaced by the blur's zero padding together with the columns outside
     // the image.  So the row body is straight-line code: no per-row branch around the arithmetic.
-#define MARCH_LOAD(J)                                                \
-    {                                                                \
-        rok[J] = load_row >= 0 && load_row < h;                      \
-        if (CACHED) march_load<false>(raw0[J], c0, rok[J]);          \
-        else march_load<U8>(raw0[J], c0, rok[J]);                    \
-        if (TWO) march_load<U8>(raw1[J], c1, rok[J]);                \
-        ++load_row;                                                  \
+#define MARCH_LOAD(J)                                                      \
+    {                                                                      \
+        const bool lok_ = (unsigned)load_row < (unsigned)h; /* uniform */  \
+        if (CACHED) march_load<false>(raw0[J], c0, lok_);                  \
+        else march_load<U8>(raw0[J], c0, lok_);                            \
+        if (TWO) march_load<U8>(raw1[J], c1, lok_);                        \
+        ++load_row;                                                        \
     }
 #define MARCH_LUT(J)                                                             \
     if (U8) {                                                                    \
         if (LUT0) march_lut(lut, raw0[J][0], c0.shift, lin0);                    \
         if (TWO) march_lut(lut, raw1[J][0], c1.shift, lin1);                     \
     }
-#define MARCH_PUT(J, SLOT)                                                                     \
+#define MARCH_PUT(J, R)                                                                        \
     {                                                                                          \
+        /* is ring row R inside the image?  (uniform, from scalars: keeps the test on the */   \
+        /* scalar unit instead of a flag carried in a vector register) */                      \
+        const bool rok_ = (unsigned)(y0 - RAD + (R)) < (unsigned)h;                            \
         float a_[3] = {0.f, 0.f, 0.f}, b_[3] = {0.f, 0.f, 0.f};                                \
         float m0_[3], m1_[3];                                                                  \
         if (!CACHED) {                                                                         \
@@ -502,14 +509,16 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
             mixed_to_xyb_pos(m0_, a_);                                                         \
         }                                                                                      \
         if (TWO) mixed_to_xyb_pos(m1_, b_);                                                    \
-        if (!(all_cols && rok[J])) { /* uniform */                                             \
-            const bool keep_ = col_ok && rok[J];                                               \
+        if (!(all_cols && rok_)) { /* uniform; the asm keeps it a branch, not 12 selects */    \
+            asm volatile("; zero padding");                                                    \
+            const bool keep_ = col_ok && rok_;                                                 \
             _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                                 \
                 a_[c_] = keep_ ? a_[c_] : 0.0f;                                                \
                 b_[c_] = keep_ ? b_[c_] : 0.0f;                                                \
             }                                                                                  \
         }                                                                                      \
-        _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) ring[SLOT][c_][col] = f2{a_[c_], b_[c_]}; \
+        _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_)                                       \
+            ring[(R) & (RING - 1)][c_][col] = f2{a_[c_], b_[c_]};                              \
     }
 #pragma unroll
     for (int j = 0; j < GROUP; ++j) MARCH_LOAD(j)  // rows 0 .. GROUP-1
@@ -522,7 +531,7 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
         for (int j = 0; j < GROUP; ++j) {
             const int r = g * GROUP + j;  // ring row to produce (uniform)
             if (r < steps) {
-                MARCH_PUT(j, r & (RING - 1))
+                MARCH_PUT(j, r)
                 MARCH_LOAD(j)  // row r + GROUP
             }
         }
@@ -653,7 +662,8 @@ __device__ __forceinline__ void march_v(const lds_vu64* rp, float (&win)[5][9], 
     d = fmaxf(d, 0.0f);
     const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
     float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
-    if (edge) {
+    if (edge) {  // uniform; the asm keeps it a branch
+        asm volatile("; right image edge");
         d = ok ? d : 0.0f;  // column inside the image?
         e = ok ? e : 0.0f;
     }
