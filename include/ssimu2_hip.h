@@ -61,6 +61,11 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx);
    load and the first encode (main.zig:62-101, tq.zig:24).  Harmless to call twice or without a
    GPU (ssimu2_ctx_create then reports SSIMU2_ERR_NO_DEVICE as usual). */
 int ssimu2_prefetch(int device);
+/* Wait until a prefetch started for `device` has finished (returns at once if there is none).
+   A process that called ssimu2_prefetch and then exits early -- before it ever creates a context
+   -- calls this first, so that HIP start-up on the background thread does not race process
+   teardown.  ssimu2_ctx_create does the same wait by itself. */
+int ssimu2_prefetch_join(int device);
 void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
 
 /* Human-readable description of the last error on this ctx ("" if none).  The pointer
@@ -122,38 +127,7 @@ int ssimu2_enqueue_against_reference_device(ssimu2_ctx* ctx, const void* d_dist)
 int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_STATS_PER_SCALE],
                          int* out_num_scales);
 
-/* Parity hook for tests: download one intermediate plane set of the last score / reference.
-   `what`: SSIMU2_DEBUG_LIN_REF / _LIN_DIST = linear-light pyramid level `scale` (1..5) of the
-   reference / distorted frame, SSIMU2_DEBUG_XYB_REF = cached positive-XYB planes of the
-   reference at `scale` (0..5; needs ssimu2_set_reference).  `out` receives 3 planes of
-   w_s*h_s floats; returns SSIMU2_ERR_INVALID_ARG if that level does not exist. */
-enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2 };
-int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
-                          uint32_t* out_w, uint32_t* out_h);
-
-/* Timing hook for bench.py: enqueue `iters` back-to-back scores of the same device pair
-   bracketed by HIP events on the ctx stream; returns total device milliseconds. */
-int ssimu2_time_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
-                       uint32_t h, int iters, float* out_ms_total, double* out_score);
-
-/* Roofline hook for bench.py: average device milliseconds of one execution of a stage of
-   the score, measured with HIP events on the ctx stream around `iters` back-to-back
-   repetitions of that stage alone (a full score runs first so every input is valid).
-   SSIMU2_STAGE_MARCH is the single fused launch that covers all six scales (the dominant
-   kernel); SSIMU2_STAGE_PYRAMID the 1-2 launches that build the linear-light pyramid;
-   SSIMU2_STAGE_FINALIZE the final reduction. */
-enum { SSIMU2_STAGE_PYRAMID = 0, SSIMU2_STAGE_MARCH = 1, SSIMU2_STAGE_FINALIZE = 2 };
-int ssimu2_time_stage(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
-                      uint32_t h, int stage, int iters, float* out_ms_avg);
-
-/* Measurement aid: the HBM read-stream ceiling of the ctx's device, measured with a plain
-   grid-stride 16-byte-per-lane read kernel over a scratch buffer of `bytes` (use well over the
-   256 MB Infinity Cache, e.g. 2 GiB), `iters` launches on the ctx stream timed with HIP events.
-   *out_gbps = bytes / average launch time.  bench.py reports the kernels' achieved bandwidth
-   against this measured figure next to the nominal 8 TB/s. */
-int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double* out_gbps);
-
-/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v1". */
+/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v4 (...)". */
 const char* ssimu2_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,65 @@
+/*
+ * ssimu2_hip_internal.h -- measurement and parity hooks of the MI355X SSIMULACRA2 scorer.
+ *
+ * NOT part of the drop-in boundary (include/ssimu2_hip.h) and NOT exported by liboavif_hip.so.
+ * These entry points live in liboavif_hip_instr.so, a second build of the same scorer sources
+ * (oavif_amd/csrc/ssimu2_instrument.hip) loaded only by bench.py, scripts/ and the tests that
+ * compare intermediate planes.  Contexts of the two libraries are not interchangeable.
+ */
+#ifndef SSIMU2_HIP_INTERNAL_H_
+#define SSIMU2_HIP_INTERNAL_H_
+
+#include "ssimu2_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Parity hook: download one intermediate plane set of the last score / reference.
+   `what`: SSIMU2_DEBUG_LIN_REF / _LIN_DIST = linear-light pyramid level `scale` (1..5) of the
+   reference / distorted frame, SSIMU2_DEBUG_XYB_REF = cached positive-XYB planes of the
+   reference at `scale` (0..5; needs ssimu2_set_reference).  `out` receives 3 planes of
+   w_s*h_s floats; returns SSIMU2_ERR_INVALID_ARG if that level does not exist. */
+enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2 };
+int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
+                          uint32_t* out_w, uint32_t* out_h);
+
+/* Timing hook: enqueue `iters` back-to-back scores of the same device pair bracketed by HIP
+   events on the ctx stream; returns total device milliseconds. */
+int ssimu2_time_device(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w,
+                       uint32_t h, int iters, float* out_ms_total, double* out_score);
+
+/* Roofline hook: average device milliseconds of one execution of a stage of the score,
+   measured with HIP events on the ctx stream around `iters` back-to-back repetitions of that
+   stage alone (a full score runs first so every input is valid).  SSIMU2_STAGE_MARCH is the
+   single fused launch that covers all six scales (the dominant kernel); SSIMU2_STAGE_PYRAMID
+   the 1-2 launches that build the linear-light pyramid; SSIMU2_STAGE_FINALIZE the final
+   reduction. */
+enum { SSIMU2_STAGE_PYRAMID = 0, SSIMU2_STAGE_MARCH = 1, SSIMU2_STAGE_FINALIZE = 2 };
+int ssimu2_time_stage(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, uint32_t w, uint32_t h,
+                      int stage, int iters, float* out_ms_avg);
+
+/* The same for the dominant kernel only, rotating over `npairs` distinct device-resident pairs
+   (d_refs[i], d_dists[i]; all w x h) so that the inputs of consecutive launches come from HBM,
+   not from the 256 MiB Infinity Cache: launch j reads pair j % npairs.  The linear-light pyramids
+   of all pairs are built first (not timed) into scratch owned by this call. */
+int ssimu2_time_march_rotating(ssimu2_ctx* ctx, const void* const* d_refs, const void* const* d_dists,
+                               int npairs, uint32_t w, uint32_t h, int iters, float* out_ms_avg);
+
+/* Measurement aid: the HBM read-stream ceiling of the ctx's device, measured with a plain
+   16-byte-per-lane read kernel over a scratch buffer of `bytes` (use well over the 256 MiB
+   Infinity Cache, e.g. 2 GiB), `iters` launches on the ctx stream timed with HIP events.
+   *out_gbps = bytes / average launch time. */
+int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double* out_gbps);
+
+/* Experiment knobs (the product always uses the defaults).  Segment rows: rows per workgroup of
+   the marching kernel at scale 0 / at the other scales, 8..160, 0 = the default rule; they only
+   regroup the fp64 partial sums (last bits of the score).  Reference blur cache: whether
+   ssimu2_set_reference also caches blur(ref*ref). */
+int ssimu2_instr_set_segment_rows(ssimu2_ctx* ctx, int rows_scale0, int rows_other_scales);
+int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSIMU2_HIP_INTERNAL_H_ */

@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OAVIF_AMD_LIB") or os.path.join(_HERE, "lib", "liboavif_hip.so")
+# the same scorer sources plus the hooks of include/ssimu2_hip_internal.h: bench / scripts / a few tests
+INSTR_LIB_PATH = os.environ.get("OAVIF_AMD_INSTR_LIB") or os.path.join(_HERE, "lib", "liboavif_hip_instr.so")
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -24,14 +26,14 @@ NUM_SCALES = 6
 STATS_PER_SCALE = 18
 TQ_MAX_PASS = 12
 
-# every symbol the headers declare; tests/test_abi.py checks the .so exports all of them
+# every symbol the public headers declare; tests/test_abi.py checks that liboavif_hip.so exports
+# exactly these (and that the Zig shim / INTEGRATION.md bind nothing else)
 EXPORTED_SYMBOLS = (
-    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_ctx_destroy", "ssimu2_last_error", "ssimu2_score_rgb8",
-    "ssimu2_set_reference", "ssimu2_score_against_reference",
+    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_last_error",
+    "ssimu2_score_rgb8", "ssimu2_set_reference", "ssimu2_score_against_reference",
     "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
-    "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages", "ssimu2_debug_download", "ssimu2_time_device",
-    "ssimu2_time_stage", "ssimu2_measure_read_stream",
+    "ssimu2_enqueue_rgb8_device", "ssimu2_wait", "ssimu2_last_averages",
     "ssimu2_version",
     "oavif_tq_default_options", "oavif_tq_predict_q_from_score",
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
@@ -64,6 +66,11 @@ class TQSpecStats(ctypes.Structure):
                 ("cache_hits", ctypes.c_uint32)]
 
 
+# include/ssimu2_hip_internal.h: only liboavif_hip_instr.so has these
+INSTR_SYMBOLS = ("ssimu2_debug_download", "ssimu2_time_device", "ssimu2_time_stage",
+                 "ssimu2_time_march_rotating", "ssimu2_measure_read_stream",
+                 "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur")
+
 TQ_MAX_FANOUT = 16
 BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
                                   ctypes.c_uint32, ctypes.POINTER(ctypes.c_double))
@@ -73,15 +80,29 @@ CODEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
                             ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_size_t))
 
 _lib = None
+_instr = None
 
 
 def lib() -> ctypes.CDLL:
+    """The product library (what a caller of the C ABI links)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _load(LIB_PATH, False)
+    return _lib
+
+
+def instr_lib() -> ctypes.CDLL:
+    """The instrumented build (include/ssimu2_hip_internal.h); never used by the product path."""
+    global _instr
+    if _instr is None:
+        _instr = _load(INSTR_LIB_PATH, True)
+    return _instr
+
+
+def _load(path: str, instrumented: bool) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m oavif_amd.build` "
+            f"{path} is missing: build it with `python -m oavif_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the scorer.")
     # PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 (same SONAME as /opt/rocm's).
     # Whichever HIP runtime is loaded first serves the whole process, and torch cannot
@@ -92,13 +113,16 @@ def lib() -> ctypes.CDLL:
             import torch  # noqa: F401
         except Exception:
             pass
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, u8p, f64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_double)
     u32, ci = ctypes.c_uint32, ctypes.c_int
     L.ssimu2_ctx_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
     L.ssimu2_ctx_create.restype = ci
     L.ssimu2_prefetch.argtypes = [ci]
     L.ssimu2_prefetch.restype = ci
+    if hasattr(L, "ssimu2_prefetch_join"):
+        L.ssimu2_prefetch_join.argtypes = [ci]
+        L.ssimu2_prefetch_join.restype = ci
     L.ssimu2_ctx_destroy.argtypes = [vp]
     L.ssimu2_ctx_destroy.restype = None
     L.ssimu2_last_error.argtypes = [vp]
@@ -109,8 +133,6 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_set_reference.restype = ci
     L.ssimu2_score_against_reference.argtypes = [vp, u8p, f64p]
     L.ssimu2_score_against_reference.restype = ci
-    L.ssimu2_measure_read_stream.argtypes = [vp, ctypes.c_size_t, ci, f64p]
-    L.ssimu2_measure_read_stream.restype = ci
     L.ssimu2_score_against_reference_strided.argtypes = [vp, u8p, u32, u32, f64p]
     L.ssimu2_score_against_reference_strided.restype = ci
     L.ssimu2_set_reference_device.argtypes = [vp, vp, u32, u32]
@@ -125,13 +147,22 @@ def lib() -> ctypes.CDLL:
     L.ssimu2_wait.restype = ci
     L.ssimu2_last_averages.argtypes = [vp, f64p, ctypes.POINTER(ci)]
     L.ssimu2_last_averages.restype = ci
-    L.ssimu2_debug_download.argtypes = [vp, ci, ci, u32, u32, ctypes.POINTER(ctypes.c_float),
-                                        ctypes.POINTER(u32), ctypes.POINTER(u32)]
-    L.ssimu2_debug_download.restype = ci
-    L.ssimu2_time_device.argtypes = [vp, vp, vp, u32, u32, ci, ctypes.POINTER(ctypes.c_float), f64p]
-    L.ssimu2_time_device.restype = ci
-    L.ssimu2_time_stage.argtypes = [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)]
-    L.ssimu2_time_stage.restype = ci
+    if instrumented:
+        sigs = {
+            "ssimu2_measure_read_stream": [vp, ctypes.c_size_t, ci, f64p],
+            "ssimu2_debug_download": [vp, ci, ci, u32, u32, ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(u32), ctypes.POINTER(u32)],
+            "ssimu2_time_device": [vp, vp, vp, u32, u32, ci, ctypes.POINTER(ctypes.c_float), f64p],
+            "ssimu2_time_stage": [vp, vp, vp, u32, u32, ci, ci, ctypes.POINTER(ctypes.c_float)],
+            "ssimu2_time_march_rotating": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, u32, u32, ci,
+                                           ctypes.POINTER(ctypes.c_float)],
+            "ssimu2_instr_set_segment_rows": [vp, ci, ci],
+            "ssimu2_instr_cache_reference_blur": [vp, ci],
+        }
+        for name, argtypes in sigs.items():
+            if hasattr(L, name):  # scripts/gpu_ab.py also binds older builds that lack some hooks
+                getattr(L, name).argtypes = argtypes
+                getattr(L, name).restype = ci
     L.ssimu2_version.argtypes = []
     L.ssimu2_version.restype = ctypes.c_char_p
     L.oavif_tq_default_options.argtypes = [ctypes.POINTER(TQOptions)]
@@ -157,5 +188,4 @@ def lib() -> ctypes.CDLL:
     L.oavif_tq_search_hip.argtypes = [ctypes.POINTER(TQOptions), vp, u8p, u32, u32, CODEC_FN, vp,
                                       ctypes.POINTER(TQResult), ctypes.POINTER(ctypes.c_size_t)]
     L.oavif_tq_search_hip.restype = ci
-    _lib = L
     return L

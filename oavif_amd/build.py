@@ -13,8 +13,10 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip.so")
+LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip.so")              # the product: C ABI of include/ssimu2_hip.h, oavif_tq.h
+INSTR_LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip_instr.so")  # + include/ssimu2_hip_internal.h (bench / tests only)
 SOURCES = ["ssimu2_hip.hip", "tq.cpp"]
+INSTR_SOURCES = ["ssimu2_instrument.hip", "tq.cpp"]  # ssimu2_instrument.hip includes ssimu2_hip.hip
 
 
 def _hipcc() -> str:
@@ -25,9 +27,9 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(INSTR_LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(INSTR_LIB_PATH))
     deps = [os.path.join(CSRC, s) for s in os.listdir(CSRC)]
     inc = os.path.join(os.path.dirname(_HERE), "include")
     deps += [os.path.join(inc, s) for s in os.listdir(inc)]
@@ -45,20 +47,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
             return LIB_PATH
-        tmp = LIB_PATH + f".tmp{os.getpid()}"
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
-               "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
-               "-Wall", "-Wno-unused-function", "-o", tmp]
-        cmd += [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        try:
-            subprocess.run(cmd, check=True)
-            os.replace(tmp, LIB_PATH)
-        finally:
-            if os.path.exists(tmp):
-                os.unlink(tmp)
+        for target, sources in ((LIB_PATH, SOURCES), (INSTR_LIB_PATH, INSTR_SOURCES)):
+            tmp = target + f".tmp{os.getpid()}"
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
+                   "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
+                   "-Wall", "-Wno-unused-function", "-o", tmp]
+            cmd += [os.path.join(CSRC, s) for s in sources]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, target)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
     return LIB_PATH
 
 

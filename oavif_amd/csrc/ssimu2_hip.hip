@@ -149,8 +149,10 @@ struct ssimu2_ctx {
     bool pending = false;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // measurement builds only (ssimu2_instrument.hip); always 0 / true in the product library
     int seg_rows_override = 0;
-    int seg_rows_tail_override = 0;  // scales >= 1 (experiments)
+    int seg_rows_tail_override = 0;
+    bool cache_ref_blur = true;
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
@@ -388,7 +390,7 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v3 (merged marching launch)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v4 (pair ring, b64 taps, dword pixel loads)"; }
 
 const char* ssimu2_last_error(const ssimu2_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
@@ -414,6 +416,17 @@ int ssimu2_prefetch(int device) {
     } catch (...) {
         return SSIMU2_ERR_OOM;
     }
+    return SSIMU2_OK;
+}
+
+int ssimu2_prefetch_join(int device) {
+    if (device < 0 || device >= 64) return SSIMU2_ERR_INVALID_ARG;
+    std::shared_future<void> f;
+    {
+        std::lock_guard<std::mutex> lock(g_prefetch_mu);
+        f = g_prefetch[device];
+    }
+    if (f.valid()) f.wait();
     return SSIMU2_OK;
 }
 
@@ -443,8 +456,6 @@ static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     ssimu2_ctx* c = new (std::nothrow) ssimu2_ctx();
     if (!c) return SSIMU2_ERR_OOM;
     c->device = device;
-    if (const char* k = getenv("OAVIF_AMD_SEG_ROWS")) c->seg_rows_override = atoi(k);
-    if (const char* k = getenv("OAVIF_AMD_SEG_ROWS_TAIL")) c->seg_rows_tail_override = atoi(k);
 #define CREATE_TRY(call)                                                        \
     do {                                                                        \
         hipError_t e2 = (call);                                                 \
@@ -593,7 +604,7 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
     }
     // ... and blur(ref*ref) at every scale, which depends on the reference alone: the per-pass
     // kernel then blurs four planes instead of five (caching blur(ref) too was measured slower)
-    if (c->d_xyb_ref && getenv("OAVIF_AMD_NO_REF_BLUR") == nullptr) {
+    if (c->d_xyb_ref && c->cache_ref_blur) {
         if (need_xyb > c->cap_blur) {
             (void)hipFree(c->d_ref_blur);
             c->d_ref_blur = nullptr;
@@ -702,117 +713,6 @@ int ssimu2_last_averages(ssimu2_ctx* c, double* out, int* out_num_scales) {
     memcpy(out, c->h_result, 108 * sizeof(double));
     if (out_num_scales) *out_num_scales = (int)c->h_result[109];
     return SSIMU2_OK;
-}
-
-int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32_t h, float* out,
-                          uint32_t* out_w, uint32_t* out_h) {
-    if (!c || !out) return SSIMU2_ERR_INVALID_ARG;
-    if (w == 0 || h == 0) return c->fail(SSIMU2_ERR_INVALID_ARG, "zero image dimension");
-    const Pyramid p = make_pyramid(w, h);
-    const float* src = nullptr;
-    if (what == SSIMU2_DEBUG_LIN_REF || what == SSIMU2_DEBUG_LIN_DIST) {
-        if (scale < 1 || scale >= p.nscales || !c->d_lin_ref) return c->fail(SSIMU2_ERR_INVALID_ARG, "no such level");
-        src = (what == SSIMU2_DEBUG_LIN_REF ? c->d_lin_ref : c->d_lin_dist) + p.lin_off[scale];
-    } else if (what == SSIMU2_DEBUG_XYB_REF) {
-        if (scale < 0 || scale >= p.nscales || !c->d_xyb_ref || !c->have_ref || c->ref_w != w || c->ref_h != h)
-            return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference XYB for that level");
-        src = c->d_xyb_ref + xyb_off(p, scale);
-    } else {
-        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad `what`");
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const size_t n = (size_t)3 * p.w[scale] * p.h[scale];
-    HIP_TRY(c, hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_w) *out_w = (uint32_t)p.w[scale];
-    if (out_h) *out_h = (uint32_t)p.h[scale];
-    return SSIMU2_OK;
-}
-
-int ssimu2_time_device(ssimu2_ctx* c, const void* d_ref, const void* d_dist, uint32_t w,
-                       uint32_t h, int iters, float* out_ms_total, double* out_score) {
-    int rc = check_args(c, d_ref, d_dist, w, h);
-    if (rc) return rc;
-    if (iters <= 0 || !out_ms_total) return c->fail(SSIMU2_ERR_INVALID_ARG, "bad iters/out");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if ((rc = ensure_capacity(c, w, h))) return rc;
-    c->have_ref = false;
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < iters; ++i)
-        if ((rc = enqueue_score(c, (const uint8_t*)d_ref, (const uint8_t*)d_dist, w, h, false)))
-            return rc;
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    double score = 0.0;
-    if ((rc = ssimu2_wait(c, &score))) return rc;
-    HIP_TRY(c, hipEventSynchronize(c->ev1));
-    HIP_TRY(c, hipEventElapsedTime(out_ms_total, c->ev0, c->ev1));
-    if (out_score) *out_score = score;
-    return SSIMU2_OK;
-}
-
-int ssimu2_time_stage(ssimu2_ctx* c, const void* d_ref, const void* d_dist, uint32_t w, uint32_t h,
-                      int stage, int iters, float* out_ms_avg) {
-    int rc = check_args(c, d_ref, d_dist, w, h);
-    if (rc) return rc;
-    if (iters <= 0 || !out_ms_avg) return c->fail(SSIMU2_ERR_INVALID_ARG, "bad iters/out");
-    double score;
-    if ((rc = ssimu2_score_rgb8_device(c, d_ref, d_dist, w, h, &score))) return rc;  // valid inputs
-    const Pyramid p = make_pyramid(w, h);
-    MarchPlan mp;
-    FinalizeArgs fa;
-    int blocks = 0;
-    build_plans(c, p, (const uint8_t*)d_ref, (const uint8_t*)d_dist, false, &mp, &fa, &blocks);
-    if (stage < 0 || stage > 2) return c->fail(SSIMU2_ERR_INVALID_ARG, "bad stage");
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < iters; ++i) {
-        if (stage == SSIMU2_STAGE_PYRAMID && p.nscales > 1) {
-            const uint8_t* frames[2] = {(const uint8_t*)d_ref, (const uint8_t*)d_dist};
-            float* lin[2] = {c->d_lin_ref, c->d_lin_dist};
-            launch_pyramid(c, p, 2, frames, lin);
-        } else if (stage == SSIMU2_STAGE_MARCH && blocks > 0) {
-            hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
-        } else if (stage == SSIMU2_STAGE_FINALIZE) {
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
-        }
-    }
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventSynchronize(c->ev1));
-    float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    *out_ms_avg = ms / (float)iters;
-    return SSIMU2_OK;
-}
-
-int ssimu2_measure_read_stream(ssimu2_ctx* c, size_t bytes, int iters, double* out_gbps) {
-    if (!c) return SSIMU2_ERR_INVALID_ARG;
-    if (bytes < (1u << 20) || iters <= 0 || !out_gbps)
-        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad bytes/iters/out");
-    HIP_TRY(c, hipSetDevice(c->device));
-    void* buf = nullptr;
-    hipError_t e = hipMalloc(&buf, bytes + 64);
-    if (e != hipSuccess) return c->fail(SSIMU2_ERR_OOM, "hipMalloc(read-stream scratch)", e);
-    uint32_t* sink = (uint32_t*)((uint8_t*)buf + (bytes & ~(size_t)15));
-    int rc = SSIMU2_OK;
-    float ms = 0.f;
-    const size_t n16 = bytes / 16;
-    const int grid = 256 * 16;  // 16 workgroups of 4 waves per CU: the CUs' full wave capacity
-    if ((e = hipMemsetAsync(buf, 0, bytes + 64, c->stream)) != hipSuccess) goto hip_fail;
-    hipLaunchKernelGGL(k_read_stream, dim3(grid), dim3(256), 0, c->stream, (const uint4*)buf, n16, sink);
-    if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) goto hip_fail;
-    for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(k_read_stream, dim3(grid), dim3(256), 0, c->stream, (const uint4*)buf, n16, sink);
-    if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) goto hip_fail;
-    if ((e = hipGetLastError()) != hipSuccess) goto hip_fail;
-    if ((e = hipEventSynchronize(c->ev1)) != hipSuccess) goto hip_fail;
-    if ((e = hipEventElapsedTime(&ms, c->ev0, c->ev1)) != hipSuccess) goto hip_fail;
-    *out_gbps = (double)(n16 * 16) / ((double)ms / iters * 1e-3) * 1e-9;
-    (void)hipFree(buf);
-    return rc;
-hip_fail:
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(buf);
-    return c->fail(SSIMU2_ERR_HIP, "read-stream probe", e);
 }
 
 }  // extern "C"

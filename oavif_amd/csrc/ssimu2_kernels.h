@@ -906,32 +906,4 @@ __global__ __launch_bounds__(256) void k_unpack_rgb(const uint8_t* __restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Read-stream probe (ssimu2_measure_read_stream): every lane reads 16 bytes per step, four steps
-// in flight; the xor of everything read is stored only if it is a value the zeroed
-// buffer cannot produce, so the loads are kept and nothing is written.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_read_stream(const uint4* __restrict__ src, size_t n16,
-                                                     uint32_t* __restrict__ sink) {
-    // one contiguous chunk per workgroup (whole DRAM pages per workgroup), lanes 16 B apart
-    const size_t chunk = (n16 + gridDim.x - 1) / gridDim.x;
-    const size_t lo = (size_t)blockIdx.x * chunk;
-    const size_t hi = lo + chunk < n16 ? lo + chunk : n16;
-    size_t i = lo + threadIdx.x;
-    uint4 acc = make_uint4(0, 0, 0, 0);
-    for (; i + 768 < hi; i += 1024) {
-        const uint4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
-        acc.x ^= a.x ^ b.x ^ c.x ^ d.x;
-        acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
-        acc.z ^= a.z ^ b.z ^ c.z ^ d.z;
-        acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
-    }
-    for (; i < hi; i += 256) {
-        const uint4 a = src[i];
-        acc.x ^= a.x; acc.y ^= a.y; acc.z ^= a.z; acc.w ^= a.w;
-    }
-    const uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
-    if (v == 0x9E3779B9u) *sink = v;
-}
-
 }  // namespace ssimu2

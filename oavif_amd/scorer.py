@@ -34,8 +34,12 @@ def _check_rgb8(a, name: str) -> np.ndarray:
 class Ssimu2:
     """One scorer context = one HIP stream + device scratch (not re-entrant)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
-        self._L = _lib.lib()
+    def __init__(self, device: int = 0, stream: int | None = None, instrumented: bool = False):
+        """`instrumented=True` binds liboavif_hip_instr.so (the hooks of
+        include/ssimu2_hip_internal.h: stage timing, plane download, experiment knobs); the
+        default is the product library, which has none of them."""
+        self.instrumented = bool(instrumented)
+        self._L = _lib.instr_lib() if instrumented else _lib.lib()
         self._ctx = ctypes.c_void_p()
         rc = self._L.ssimu2_ctx_create(int(device), ctypes.c_void_p(stream or 0),
                                        ctypes.byref(self._ctx))
@@ -157,8 +161,14 @@ class Ssimu2:
             self._raise(rc)
         return out.value
 
+    # -- measurement / parity hooks: instrumented build only ------------------------------------
+    def _need_instr(self):
+        if not self.instrumented:
+            raise RuntimeError("this hook needs Ssimu2(..., instrumented=True) (liboavif_hip_instr.so)")
+
     def time_device(self, d_ref: int, d_dist: int, w: int, h: int, iters: int):
         """-> (total device ms for `iters` back-to-back scores, score)."""
+        self._need_instr()
         ms = ctypes.c_float()
         out = ctypes.c_double()
         rc = self._L.ssimu2_time_device(self._ctx, ctypes.c_void_p(d_ref), ctypes.c_void_p(d_dist),
@@ -169,6 +179,7 @@ class Ssimu2:
 
     def time_stage(self, d_ref: int, d_dist: int, w: int, h: int, stage: int, iters: int) -> float:
         """-> average device ms of one execution of `stage` (_lib.STAGE_*) of the score."""
+        self._need_instr()
         ms = ctypes.c_float()
         rc = self._L.ssimu2_time_stage(self._ctx, ctypes.c_void_p(d_ref), ctypes.c_void_p(d_dist),
                                        w, h, stage, iters, ctypes.byref(ms))
@@ -178,6 +189,7 @@ class Ssimu2:
 
     def measure_read_stream(self, nbytes: int = 2 << 30, iters: int = 10) -> float:
         """-> measured HBM read-stream bandwidth of the device in GB/s (ssimu2_measure_read_stream)."""
+        self._need_instr()
         out = ctypes.c_double()
         rc = self._L.ssimu2_measure_read_stream(self._ctx, ctypes.c_size_t(nbytes), iters,
                                                 ctypes.byref(out))
@@ -187,6 +199,7 @@ class Ssimu2:
 
     def debug_download(self, what: int, scale: int, w: int, h: int) -> np.ndarray:
         """-> (3, h_s, w_s) float32 planes (see ssimu2_debug_download)."""
+        self._need_instr()
         sw, sh = w, h
         for _ in range(scale):
             sw, sh = (sw + 1) // 2, (sh + 1) // 2
@@ -199,6 +212,32 @@ class Ssimu2:
             self._raise(rc)
         assert (ow.value, oh.value) == (sw, sh)
         return out
+
+    def time_march_rotating(self, d_refs, d_dists, w: int, h: int, iters: int) -> float:
+        """-> average device ms of the marching kernel over `iters` launches that rotate over the
+        device-resident pairs (d_refs[i], d_dists[i]) -- inputs from HBM, not from the Infinity Cache."""
+        self._need_instr()
+        n = len(d_refs)
+        assert n == len(d_dists) and n > 0
+        arr = ctypes.c_void_p * n
+        ms = ctypes.c_float()
+        rc = self._L.ssimu2_time_march_rotating(self._ctx, arr(*d_refs), arr(*d_dists), n, w, h, iters,
+                                                ctypes.byref(ms))
+        if rc != 0:
+            self._raise(rc)
+        return ms.value
+
+    def set_segment_rows(self, rows_scale0: int, rows_other_scales: int) -> None:
+        self._need_instr()
+        rc = self._L.ssimu2_instr_set_segment_rows(self._ctx, rows_scale0, rows_other_scales)
+        if rc != 0:
+            self._raise(rc)
+
+    def cache_reference_blur(self, enabled: bool) -> None:
+        self._need_instr()
+        rc = self._L.ssimu2_instr_cache_reference_blur(self._ctx, 1 if enabled else 0)
+        if rc != 0:
+            self._raise(rc)
 
     def last_averages(self):
         """-> ((6, 18) float64 plane averages of the last score, number of scales)."""

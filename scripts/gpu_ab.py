@@ -2,7 +2,11 @@
 of scores, so that a faster build can be shown to return the same doubles.
 
     python scripts/gpu_ab.py libA.so libB.so ...        (driver: one child process per library)
-    OAVIF_AMD_LIB=lib.so python scripts/gpu_ab.py --one (child)
+    OAVIF_AMD_INSTR_LIB=lib.so python scripts/gpu_ab.py --one (child)
+
+Every library must carry the timing hooks (include/ssimu2_hip_internal.h): an instrumented
+build (oavif_amd/lib/liboavif_hip_instr.so, or `hipcc ... ssimu2_instrument.hip tq.cpp`), or a
+round-1 build, whose product library still had them.
 
 Each child prints `bits <case> <hex of score> <sha of the 108 averages>` lines and timing lines;
 the driver diffs the bits lines against the first library's.
@@ -26,8 +30,8 @@ def child():
     import torch
     import oavif_amd
     from oavif_amd import synth
-    s = oavif_amd.Ssimu2(0)
-    print("version", oavif_amd.version(), flush=True)
+    s = oavif_amd.Ssimu2(0, instrumented=True)
+    print("version", s._L.ssimu2_version().decode(), flush=True)
     for (w, h, kind, strength) in CASES:
         ref = synth.make_ref(w, h, w * 7 + h)
         dst = synth.distort(ref, kind, strength, seed=3)
@@ -82,7 +86,7 @@ def main():
     base = None
     rc = 0
     for lib in libs:
-        env = dict(os.environ, OAVIF_AMD_LIB=os.path.abspath(lib))
+        env = dict(os.environ, OAVIF_AMD_INSTR_LIB=os.path.abspath(lib))
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env,
                            capture_output=True, text=True, timeout=600)
         print(f"==== {lib} rc={p.returncode}")

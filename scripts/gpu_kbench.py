@@ -1,28 +1,58 @@
-"""Kernel micro-bench on the GPU box: per-scale fused-kernel time and whole-score time at 4K."""
-import os, sys
+"""Kernel micro-bench on the GPU box, the workload the rocprofv3 PMC passes run over
+(scripts/gpu_pmc_sets.sh): the marching kernel and whole scores at 4K ROTATING over 8 distinct
+pairs (inputs from HBM, not from the Infinity Cache), then reference-cached passes rotating over
+the 8 distorted frames.  Uses the instrumented build (stage timing hooks)."""
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-import oavif_amd
-from oavif_amd import synth
+import torch  # noqa: E402
+
+import oavif_amd  # noqa: E402
+from oavif_amd import synth  # noqa: E402
+
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-ref = synth.make_ref(w, h, 0); dst = synth.distort(ref, "blockq", 2)
-tr = torch.from_numpy(ref).cuda().contiguous(); td = torch.from_numpy(dst).cuda().contiguous()
+NP = 8
+ref = synth.make_ref(w, h, 0)
+dst = synth.distort(ref, "blockq", 2)
+tr = torch.from_numpy(ref).cuda().contiguous()
+td = torch.from_numpy(dst).cuda().contiguous()
+pairs = [(tr, td)]
+for k in range(1, NP):
+    a, b = torch.roll(tr, k * w // NP, 1), torch.roll(td, k * w // NP, 1)
+    if k & 1:
+        a, b = a.flip(0), b.flip(0)
+    pairs.append((a.contiguous(), b.contiguous()))
 torch.cuda.synchronize()
-s = oavif_amd.Ssimu2(0)
-score = s.score_device(tr.data_ptr(), td.data_ptr(), w, h)
-_, ns = s.last_averages()
-ks = [s.time_stage(tr.data_ptr(), td.data_ptr(), w, h, st, 30) * 1e3 for st in range(3)]
-ms, _ = s.time_device(tr.data_ptr(), td.data_ptr(), w, h, 50)
-tag = f"seg={os.environ.get('OAVIF_AMD_SEG_ROWS','auto')}"
-print(f"{tag}: score={score:.9f} stage_us[pyramid,march,finalize]={[round(k,1) for k in ks]} sum={sum(ks):.1f} whole_score_us={ms/50*1e3:.1f} MP/s={w*h/1e6/(ms/50/1e3):.0f}")
-s.set_reference_device(tr.data_ptr(), w, h)
-import time
-for _ in range(5):
-    s.enqueue_against_reference_device(td.data_ptr())
-sc2 = s.wait()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(100):
-    s.enqueue_against_reference_device(td.data_ptr())
-sc2 = s.wait(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
-print(f"cached-reference score: {sc2:.9f} (same={sc2 == score}) {dt*1e6:.1f} us/score  {w*h/1e6/dt:.0f} MP/s")
+pr, pd = [a.data_ptr() for a, _ in pairs], [b.data_ptr() for _, b in pairs]
+s = oavif_amd.Ssimu2(0, instrumented=True)
+score = s.score_device(pr[0], pd[0], w, h)
+for _ in range(100):  # clocks
+    s.enqueue_device(pr[0], pd[0], w, h)
+s.wait()
+k_rot = s.time_march_rotating(pr, pd, w, h, 64) * 1e3
+ks = [s.time_stage(pr[0], pd[0], w, h, st, 8) * 1e3 for st in range(3)]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 64
+for i in range(n):
+    s.enqueue_device(pr[i % NP], pd[i % NP], w, h)
+s.wait()
+dt = (time.perf_counter() - t0) / n
+print(f"kbench: score={score:.9f} march_us rotating={k_rot:.1f} cache_resident={ks[1]:.1f} "
+      f"pyramid_us={ks[0]:.1f} finalize_us={ks[2]:.1f} whole_score_us(rotating)={dt * 1e6:.1f} "
+      f"MP/s={w * h / 1e6 / dt:.0f}")
+s.set_reference_device(pr[0], w, h)
+for i in range(8):
+    s.enqueue_against_reference_device(pd[i % NP])
+s.wait()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(n):
+    s.enqueue_against_reference_device(pd[i % NP])
+s.wait()
+dt = (time.perf_counter() - t0) / n
+print(f"cached-reference pass (rotating dist frames): {dt * 1e6:.1f} us/score  {w * h / 1e6 / dt:.0f} MP/s")
+s.close()

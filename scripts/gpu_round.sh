@@ -1,7 +1,9 @@
 #!/bin/bash
-# One recorded GPU-box round: smoke, GPU tests, bench, rocprof kernel stats, PMC traffic.
-# Usage (on the box, from the repo root): scripts/gpu_round.sh TAG     (outputs in gpurun_out/TAG/)
-TAG=${1:-r01}
+# One recorded GPU-box round: smoke, GPU tests, bench, rocprof kernel stats, PMC counters, VALU
+# microbenchmark, counters.json.   Usage (on the box, repo root): scripts/gpu_round.sh TAG
+# Outputs in gpurun_out/TAG/; the summaries to keep are then copied into profiles/ by hand
+# (kernel_stats.csv -> profiles/TAG_kernel_stats.csv, pmc_summary.txt, counters.json, bench.json).
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 export OMP_NUM_THREADS=16
 mkdir -p $OUT
@@ -12,13 +14,17 @@ tail -4 $OUT/pytest_gpu.log
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/scripts/gpu_kbench.py > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/scripts/gpu_kbench.py > $OUT/pmc_write.log 2>&1; echo "pmc write rc=$?"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_calib -- $GRAFT_REPO_ROOT/scripts/ubench/fetch_calib > $OUT/pmc_calib.log 2>&1; echo "pmc calib rc=$?"
+# per-kernel durations with the scores of one stream never overlapping (two streams stretch them)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 64 --warmup 16 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
 cd $GRAFT_REPO_ROOT
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-python3 scripts/pmc_summary.py $OUT/pmc_fetch/ $OUT/pmc_write/ $OUT/pmc_calib/ > $OUT/pmc_summary.txt
-cat $OUT/kernel_stats.csv | cut -c1-150
-cat $OUT/pmc_summary.txt
-rm -rf $OUT/prof/*/*kernel_trace.csv $OUT/pmc_*/*/*kernel_trace.csv
+cut -c1-150 $OUT/kernel_stats.csv
+rm -rf $OUT/prof
+scripts/gpu_pmc_sets.sh $TAG
+timeout -k 10 200 scripts/ubench/valu_rate > $OUT/valu_rate.txt
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_calib -- $GRAFT_REPO_ROOT/scripts/ubench/fetch_calib > $OUT/pmc_calib.log 2>&1; echo "pmc calib rc=$?"
+cd $GRAFT_REPO_ROOT
+python3 scripts/pmc_summary.py $OUT/pmc_calib/ > $OUT/pmc_calib_summary.txt; rm -rf $OUT/pmc_calib
+python3 scripts/make_counters_json.py $OUT/pmc_summary.txt $OUT/valu_rate.txt > $OUT/counters.json
+cat $OUT/counters.json | head -12

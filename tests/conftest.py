@@ -47,3 +47,13 @@ def scorer(hip_lib):
     s = Ssimu2(0)
     yield s
     s.close()
+
+
+@pytest.fixture(scope="session")
+def iscorer(hip_lib):
+    """Context of the INSTRUMENTED build (liboavif_hip_instr.so: include/ssimu2_hip_internal.h);
+    only for tests that need stage timing, plane downloads or the experiment knobs."""
+    from oavif_amd import Ssimu2
+    s = Ssimu2(0, instrumented=True)
+    yield s
+    s.close()

@@ -16,16 +16,49 @@ def _declared_functions(header):
     return sorted({n for n in names if not n.endswith("_fn")})
 
 
+def _exported(path):
+    """Dynamic symbols a shared object defines (nm -D --defined-only)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
 def test_headers_and_binding_agree(hip_lib):
     from oavif_amd import _lib
     declared = set(_declared_functions("ssimu2_hip.h")) | set(_declared_functions("oavif_tq.h"))
     assert declared == set(_lib.EXPORTED_SYMBOLS)
+    assert set(_declared_functions("ssimu2_hip_internal.h")) == set(_lib.INSTR_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol(hip_lib):
     for header in ("ssimu2_hip.h", "oavif_tq.h"):
         for name in _declared_functions(header):
             assert hasattr(hip_lib, name), f"{name} declared in {header} but not exported"
+
+
+def test_product_library_exports_exactly_the_public_headers(hip_lib):
+    """The product .so carries no measurement hooks: its ssimu2_* / oavif_* exports are exactly
+    what include/ssimu2_hip.h and include/oavif_tq.h declare; the hooks of
+    include/ssimu2_hip_internal.h exist only in the instrumented build."""
+    from oavif_amd import _lib
+    public = set(_declared_functions("ssimu2_hip.h")) | set(_declared_functions("oavif_tq.h"))
+    got = {s for s in _exported(_lib.LIB_PATH) if s.startswith(("ssimu2_", "oavif_"))}
+    assert got == public, got ^ public
+    instr = {s for s in _exported(_lib.INSTR_LIB_PATH) if s.startswith(("ssimu2_", "oavif_"))}
+    assert instr == public | set(_lib.INSTR_SYMBOLS), instr ^ (public | set(_lib.INSTR_SYMBOLS))
+
+
+def test_zig_shim_and_integration_bind_only_public_symbols():
+    """Every extern the Zig shim declares, and every ssimu2_* / oavif_* name INTEGRATION.md
+    mentions, is in the public headers."""
+    public = set(_declared_functions("ssimu2_hip.h")) | set(_declared_functions("oavif_tq.h"))
+    zig = open(os.path.join(ROOT, "oavif_amd", "zig", "fssimu2.zig")).read()
+    externs = set(re.findall(r"extern\s+fn\s+((?:ssimu2|oavif)_[a-z0-9_]+)", zig))
+    assert externs and externs <= public, externs - public
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = set(re.findall(r"\b((?:ssimu2|oavif)_(?:tq_|prescale_)?[a-z0-9_]+)\s*\(", integ))
+    unknown = {n for n in names if n not in public and not n.endswith("_fn")}
+    assert not unknown, unknown
 
 
 def test_version_string(hip_lib):

@@ -128,8 +128,27 @@ def test_device_resident_entry_points(scorer):
     assert scorer.score_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300) == host
     scorer.enqueue_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300)
     assert scorer.wait() == host
-    ms, s = scorer.time_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300, 3)
+
+
+def test_instrumented_build_scores_the_same_bits(scorer, iscorer):
+    """liboavif_hip_instr.so is the product sources + hooks: same scores, and its timing hooks work."""
+    import torch
+    ref = synth.make_ref(400, 300, 51)
+    dist = synth.distort(ref, "blur", 1)
+    host = scorer.compute_ssimu2(ref, dist)
+    assert iscorer.compute_ssimu2(ref, dist) == host
+    t_ref = torch.from_numpy(ref).cuda().contiguous()
+    t_dist = torch.from_numpy(dist).cuda().contiguous()
+    torch.cuda.synchronize()
+    ms, s = iscorer.time_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300, 3)
     assert s == host and ms > 0
+    from oavif_amd import _lib
+    assert iscorer.time_stage(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300, _lib.STAGE_MARCH, 3) > 0
+    ptrs_r, ptrs_d = [t_ref.data_ptr()] * 2, [t_dist.data_ptr(), t_ref.data_ptr()]
+    assert iscorer.time_march_rotating(ptrs_r, ptrs_d, 400, 300, 4) > 0
+    assert iscorer.compute_ssimu2(ref, dist) == host          # the hooks leave the context usable
+    with pytest.raises(RuntimeError):
+        scorer.time_device(t_ref.data_ptr(), t_dist.data_ptr(), 400, 300, 3)   # not in the product
 
 
 def test_two_contexts_are_independent(hip_lib, scorer):
@@ -394,7 +413,8 @@ def test_batch_cli_with_worker_threads(hip_lib, tmp_path):
 
 
 @pytest.mark.parametrize("w,h", [(333, 217), (512, 512), (121, 9)])
-def test_intermediate_planes_are_bit_identical(scorer, oracle, w, h):
+def test_intermediate_planes_are_bit_identical(iscorer, oracle, w, h):
+    scorer = iscorer  # plane download is a hook of the instrumented build
     """Stage-by-stage parity (bit-exact, as for integer work): the linear-light pyramid of both
     frames and the cached positive-XYB planes of the reference equal the oracle's planes bit for
     bit -- the arithmetic contract (explicit fmaf order, reproducible cube root) holds per pixel,
@@ -438,17 +458,23 @@ def test_caller_owned_stream(hip_lib):
 
 
 @pytest.mark.parametrize("seg,tail", [(8, 8), (13, 21), (47, 160), (160, 9), (1, 1)])
-def test_any_segment_length_gives_the_same_score(hip_lib, scorer, seg, tail, monkeypatch):
-    """The per-workgroup row ranges (OAVIF_AMD_SEG_ROWS*) only regroup the fp64 partial sums."""
+def test_any_segment_length_gives_the_same_score(hip_lib, scorer, seg, tail):
+    """The per-workgroup row ranges (an experiment knob of the instrumented build) only regroup
+    the fp64 partial sums; values outside 8..160 are refused."""
     import oavif_amd
     ref = synth.make_ref(517, 391, 19)
     dist = synth.distort(ref, "noise", 2, seed=4)
     expect = scorer.compute_ssimu2(ref, dist)
-    monkeypatch.setenv("OAVIF_AMD_SEG_ROWS", str(seg))
-    monkeypatch.setenv("OAVIF_AMD_SEG_ROWS_TAIL", str(tail))
-    with oavif_amd.Ssimu2(0) as s:
+    with oavif_amd.Ssimu2(0, instrumented=True) as s:
+        if seg < 8 or tail < 8:
+            with pytest.raises(oavif_amd.Ssimu2Error):
+                s.set_segment_rows(seg, tail)
+            return
+        s.set_segment_rows(seg, tail)
         got = s.compute_ssimu2(ref, dist)
-    assert abs(got - expect) < 1e-7
+        assert abs(got - expect) < 1e-7
+        s.set_segment_rows(0, 0)
+        assert s.compute_ssimu2(ref, dist) == expect
 
 
 def _decoded_like(dist, channels, pad, seed):
@@ -633,7 +659,8 @@ def test_cli_probe_fanout_env_gives_the_same_file_and_lines(hip_lib, tmp_path, c
     assert outs[0][1] == outs[1][1]
 
 
-def test_read_stream_probe_reports_a_plausible_bandwidth(scorer):
+def test_read_stream_probe_reports_a_plausible_bandwidth(iscorer):
+    scorer = iscorer
     """ssimu2_measure_read_stream: between 1 and 8 TB/s on an MI355X for a 1 GiB buffer, and the
     context scores normally afterwards."""
     gbs = scorer.measure_read_stream(1 << 30, 5)
