@@ -391,39 +391,41 @@ __device__ __forceinline__ void mixed_to_xyb_pos(const float (&lms)[3], float (&
 //     load ever reaches behind the frame's last byte.
 //   fp32 planes (scales >= 1, cached reference XYB): three dword loads, `plane` elements apart.
 struct MarchCursor {
-    const uint8_t* row;  // uniform: first byte of the next row to load (advanced by the scalar unit)
-    uint32_t off;        // per lane: byte offset of this lane's pixel inside a row
-    size_t plane;        // bytes between planes (fp32 sources)
-    int pitch;           // bytes per row
-    uint32_t shift;      // u8 only
+    const uint8_t* base;  // uniform: first byte of the frame / of the first plane
+    uint32_t off;         // per lane: byte offset of this lane's pixel inside a row
+    size_t plane;         // bytes between planes (fp32 sources)
+    int pitch;            // bytes per row
+    uint32_t shift;       // u8 only
 };
 
 template <bool U8>
-__device__ __forceinline__ MarchCursor march_cursor(const void* base, int w, int h, int gxc, int first_row) {
+__device__ __forceinline__ MarchCursor march_cursor(const void* base, int w, int h, int gxc) {
     MarchCursor c;
     c.plane = (size_t)w * h * 4;
     c.pitch = U8 ? w * 3 : w * 4;
     const bool last_col = U8 && gxc == w - 1;
     c.shift = last_col ? 8u : 0u;
-    c.row = (const uint8_t*)base + (ptrdiff_t)first_row * c.pitch;
+    c.base = (const uint8_t*)base;
     c.off = (uint32_t)gxc * (U8 ? 3u : 4u) - (last_col ? 1u : 0u);
     return c;
 }
 
+// Load this lane's pixel of image row `row` (uniform; clamped into the image by the caller, so
+// the load is unconditional: every row issues the same number of loads and the compiler's
+// s_waitcnt vmcnt(N) can count them -- a conditional load made it fall back to vmcnt(0), which
+// shortened the prefetch distance to one row).
 template <bool U8>
-__device__ __forceinline__ void march_load(uint32_t (&raw)[3], MarchCursor& c, bool row_ok) {
-    if (row_ok) {  // uniform; rows outside the image are never dereferenced
-        if (U8) {
-            uint32_t d;
-            __builtin_memcpy(&d, c.row + c.off, 4);
-            raw[0] = d;
-        } else {
-            raw[0] = *(const uint32_t*)(c.row + c.off);
-            raw[1] = *(const uint32_t*)(c.row + c.plane + c.off);
-            raw[2] = *(const uint32_t*)(c.row + 2 * c.plane + c.off);
-        }
+__device__ __forceinline__ void march_load(uint32_t (&raw)[3], const MarchCursor& c, int row) {
+    const uint8_t* p = c.base + (size_t)(uint32_t)row * (uint32_t)c.pitch;
+    if (U8) {
+        uint32_t d;
+        __builtin_memcpy(&d, p + c.off, 4);
+        raw[0] = d;
+    } else {
+        raw[0] = *(const uint32_t*)(p + c.off);
+        raw[1] = *(const uint32_t*)(p + c.plane + c.off);
+        raw[2] = *(const uint32_t*)(p + 2 * c.plane + c.off);
     }
-    c.row += c.pitch;
 }
 
 __device__ __forceinline__ void march_lut(const float* lut, uint32_t d, uint32_t shift, float (&lin)[3]) {
@@ -452,28 +454,28 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
     const bool col_ok = gx >= 0 && gx < w;
     const bool all_cols = x0 - RAD >= 0 && x0 - RAD + MRW <= w;  // uniform: no lane outside the image
     const int gxc = min(max(gx, 0), w - 1);  // clamped: the value is discarded when gx is outside
-    MarchCursor c0 = CACHED ? march_cursor<false>(plan.ref_xyb[sc], w, h, gxc, y0 - RAD)
-                            : march_cursor<U8>(plan.ref[sc], w, h, gxc, y0 - RAD);
-    MarchCursor c1 = march_cursor<U8>(plan.dist[sc], w, h, gxc, y0 - RAD);
-    int load_row = y0 - RAD;  // image row the cursors point at
-    // raw[f][j]: loaded, not yet converted row of frame f; slot j is refilled every GROUP rows, so
-    // the GROUP-deep prefetch queue rotates with the unrolled group (no register moves)
-    uint32_t raw0[GROUP][3], raw1[GROUP][3];
+    const MarchCursor c0 = CACHED ? march_cursor<false>(plan.ref_xyb[sc], w, h, gxc)
+                                  : march_cursor<U8>(plan.ref[sc], w, h, gxc);
+    const MarchCursor c1 = march_cursor<U8>(plan.dist[sc], w, h, gxc);
+    int load_row = y0 - RAD;  // image row of the next load
+    // raw[f][j]: loaded, not yet converted row of frame f.  The queue is QD = 2 * GROUP rows deep
+    // (the LUT reads of a row are requested one row before it is converted, so its pixels must
+    // have landed by then: 4.5 rows = several microseconds of flight, enough for an HBM miss
+    // under load); slot j is refilled every QD rows, the loop body is unrolled QD times, so the
+    // queue rotates without register moves.
+    constexpr int QD = 2 * GROUP;
+    uint32_t raw0[QD][3], raw1[QD][3];
     float lin0[3] = {0.f, 0.f, 0.f}, lin1[3] = {0.f, 0.f, 0.f};  // LUT values of the next row to convert
-#pragma unroll
-    for (int j = 0; j < GROUP; ++j)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) raw0[j][k] = raw1[j][k] = 0;
-    // A row outside the image (only in the halo of the image's first and last segments) is not
-    // loaded -- its queue slot keeps the previous, valid row -- and is converted like any other;
-    // its values are then replaced by the blur's zero padding together with the columns outside
-    // the image.  So the row body is straight-line code: no per-row branch around the arithmetic.
+    // A row outside the image (only in the halo of the image's first and last segments) loads the
+    // nearest image row instead and is converted like any other; its values are then replaced by
+    // the blur's zero padding together with the columns outside the image.  So the row body is
+    // straight-line code: no per-row branch around the loads or the arithmetic.
 #define MARCH_LOAD(J)                                                      \
     {                                                                      \
-        const bool lok_ = (unsigned)load_row < (unsigned)h; /* uniform */  \
-        if (CACHED) march_load<false>(raw0[J], c0, lok_);                  \
-        else march_load<U8>(raw0[J], c0, lok_);                            \
-        if (TWO) march_load<U8>(raw1[J], c1, lok_);                        \
+        const int lrow_ = min(max(load_row, 0), h - 1); /* uniform */      \
+        if (CACHED) march_load<false>(raw0[J], c0, lrow_);                 \
+        else march_load<U8>(raw0[J], c0, lrow_);                           \
+        if (TWO) march_load<U8>(raw1[J], c1, lrow_);                       \
         ++load_row;                                                        \
     }
 #define MARCH_LUT(J)                                                             \
@@ -500,7 +502,7 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
         }                                                                                      \
         if (U8) {                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                 \
-            MARCH_LUT((J + 1) % GROUP)                                                         \
+            MARCH_LUT((J + 1) % QD)                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                      \
         if (CACHED) {                                                                          \
@@ -521,22 +523,32 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
             ring[(R) & (RING - 1)][c_][col] = f2{a_[c_], b_[c_]};                              \
     }
 #pragma unroll
-    for (int j = 0; j < GROUP; ++j) MARCH_LOAD(j)  // rows 0 .. GROUP-1
+    for (int j = 0; j < QD; ++j) MARCH_LOAD(j)  // rows 0 .. QD-1
     MARCH_LUT(0)
-    // iteration g produces ring rows 3g .. 3g+2 (the blur waves consume them in their iteration
-    // g, one barrier later) and loads rows 3g+3 .. 3g+5; the last iteration only joins the barrier
-#pragma unroll 1
-    for (int g = 0; g <= ngroups; ++g) {
-#pragma unroll
-        for (int j = 0; j < GROUP; ++j) {
-            const int r = g * GROUP + j;  // ring row to produce (uniform)
-            if (r < steps) {
-                MARCH_PUT(j, r)
-                MARCH_LOAD(j)  // row r + GROUP
-            }
-        }
-        __syncthreads();
+    // group g produces ring rows 3g .. 3g+2 (the blur waves consume them in their group g, one
+    // barrier later) and loads rows 3g+6 .. 3g+8; ngroups + 1 barriers in all, the last group
+    // only joins the barrier.  A partial last group converts up to two rows behind the segment
+    // into ring slots nobody reads any more.
+#define MARCH_GROUP(G, J0)                                   \
+    if ((G) * GROUP < steps) {                               \
+        MARCH_PUT(J0 + 0, (G) * GROUP + 0)                   \
+        MARCH_LOAD(J0 + 0)                                   \
+        MARCH_PUT(J0 + 1, (G) * GROUP + 1)                   \
+        MARCH_LOAD(J0 + 1)                                   \
+        MARCH_PUT(J0 + 2, (G) * GROUP + 2)                   \
+        MARCH_LOAD(J0 + 2)                                   \
     }
+    static_assert(GROUP == 3, "MARCH_GROUP is written for three rows per barrier interval");
+#pragma unroll 1
+    for (int g = 0; g <= ngroups; g += 2) {
+        MARCH_GROUP(g, 0)
+        __syncthreads();
+        if (g + 1 <= ngroups) {
+            MARCH_GROUP(g + 1, GROUP)
+            __syncthreads();
+        }
+    }
+#undef MARCH_GROUP
 #undef MARCH_LOAD
 #undef MARCH_LUT
 #undef MARCH_PUT
