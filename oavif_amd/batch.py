@@ -12,8 +12,15 @@ and number formats (measure.py:178-206), the summary statistics (measure.py:209-
 "--tolerance" / "--keep" flags, and main.zig's rule that the last probe's bytes are reused
 only when its quantizer is the chosen one (main.zig:109-113).
 
-    python -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV [--tolerance T] [--keep]
+    python -m oavif_amd.batch IMAGES_DIR [OAVIF_PATH] OUTPUT_CSV [--tolerance T] [--keep]
     python -m torch.distributed.run --nproc-per-node 8 -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV
+
+The positional arguments are measure.py's (measure.py:111-123: images_dir oavif_path output_csv),
+so an existing invocation keeps working; OAVIF_PATH is accepted and not used (the search runs in
+this process instead of one `oavif` process per image), and the two-positional form omits it.
+Every image goes through the same load / encode path as the CLI mirror (oavif_amd.cli): the
+source's own channels (alpha included), ICC profile, 16-bit >> 8, and the reference's encoder
+defaults (one encoder thread, parse_args.zig:51).
 """
 from __future__ import annotations
 
@@ -74,30 +81,42 @@ def shard(n_items: int, rank: int, world: int) -> List[int]:
 # ---- one image ---------------------------------------------------------------------------------
 
 def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float = 80.0,
-                 tolerance: float = 2.0, max_pass: int = 6, speed: int = 9):
-    """main.zig:73-116 for one file with the search on the GPU scorer.
+                 tolerance: float = 2.0, max_pass: int = 6, speed: int = 9, options=None):
+    """main.zig:73-116 for one file with the search on the GPU scorer, through the CLI mirror's
+    own load and encode functions (one path for `python -m oavif_amd.cli` and the batch).
 
     Returns (q, score, passes, final_bytes)."""
-    from PIL import Image
-
-    from . import synth, tq
-    rgb = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB")))  # Image.toRGB8
+    from . import cli, tq
+    o = options
+    if o is None:
+        o = cli.AvifEncOptions()   # the reference's defaults (parse_args.zig:48-63): 1 thread, auto tiling
+        o.speed, o.score_tgt, o.tolerance, o.max_pass = speed, score_tgt, tolerance, max_pass
+    src = cli.load_source(str(path))
     cache = {}
 
     def codec(q: int):
-        data = synth.avif_encode(rgb, q, speed)
+        data = cli._encode(src.pixels, o, q, icc=src.icc)
         cache.clear()
         cache[q] = data                      # EncBuffer holds only the last probe (tq.zig:31-35)
-        return synth.avif_decode(data), len(data)
+        return cli._decode_rgb(data), len(data)
 
-    r = tq.search_hip(scorer, rgb, codec, score_tgt=score_tgt, tolerance=tolerance,
-                      max_pass=max_pass)
+    r = tq.search_hip(scorer, src.rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                      max_pass=o.max_pass)
     data = cache.get(r.q) if r.buf_q == r.q else None
     if data is None:                         # main.zig:109-113: re-encode at the chosen q
-        data = synth.avif_encode(rgb, r.q, speed)
+        data = cli._encode(src.pixels, o, r.q, icc=src.icc)
     if out_path is not None:
         out_path.write_bytes(data)
     return r.q, r.score, r.num_pass, len(data)
+
+
+def output_names(image_files: Sequence[Path]) -> List[str]:
+    """One .avif name per input: `<stem>.avif` as measure.py writes it (measure.py:49), or
+    `<stem>_<ext>.avif` for inputs whose stem is shared (a.png + a.jpg), so that concurrent
+    workers / ranks never write the same file."""
+    stems = [p.stem for p in image_files]
+    return [f"{p.stem}.avif" if stems.count(p.stem) == 1 else f"{p.stem}_{p.suffix.lstrip('.').lower()}.avif"
+            for p in image_files]
 
 
 # ---- gather ----------------------------------------------------------------------------------------
@@ -164,12 +183,15 @@ def write_csv(path, results: Sequence[ImageResult]) -> None:
 
 
 def human_bytes(n: float) -> str:
-    size = float(n)
-    for u in ("B", "KiB", "MiB", "GiB", "TiB"):
-        if size < 1024.0 or u == "TiB":
-            return f"{size:.2f} {u}"
-        size /= 1024.0
-    return f"{size:.2f} TiB"
+    """`1536 -> "1.50 KiB"`: binary units up to TiB, two decimals (the format of measure.py's
+    summary lines, measure.py:31-38)."""
+    units = ("B", "KiB", "MiB", "GiB", "TiB")
+    k = 0
+    v = float(n)
+    while v >= 1024.0 and k < len(units) - 1:
+        v /= 1024.0
+        k += 1
+    return f"{v:.2f} {units[k]}"
 
 
 def summarize(results: Sequence[ImageResult], wall_s: float, world: int = 1) -> str:
@@ -262,11 +284,13 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
     return results
 
 
-def main(argv=None) -> int:
+def parse_cli(argv=None):
+    """measure.py's command line (measure.py:111-123) plus the search options."""
     ap = argparse.ArgumentParser(description="Target-quality AVIF encoding of a directory of images, "
                                              "sharded over the GPUs of one node")
-    ap.add_argument("images_dir")
-    ap.add_argument("output_csv")
+    ap.add_argument("paths", nargs="+", metavar="PATH",
+                    help="IMAGES_DIR OUTPUT_CSV, or measure.py's IMAGES_DIR OAVIF_PATH OUTPUT_CSV "
+                         "(OAVIF_PATH is accepted for compatibility and not used)")
     ap.add_argument("--tolerance", type=float, default=2.0)   # parse_args.zig:58
     ap.add_argument("--score-tgt", type=float, default=80.0)  # parse_args.zig:55
     ap.add_argument("--max-pass", type=int, default=6)        # parse_args.zig:59
@@ -276,6 +300,20 @@ def main(argv=None) -> int:
                     help="images encoded concurrently per rank (threads; one scorer context each)")
     ap.add_argument("--out-dir", default="temp_avif_output")
     args = ap.parse_args(argv)
+    if len(args.paths) == 2:
+        args.images_dir, args.output_csv = args.paths
+    elif len(args.paths) == 3:   # measure.py:111-123
+        args.images_dir, oavif_path, args.output_csv = args.paths
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"note: {oavif_path} is not run; the search runs in this process on the GPU scorer",
+                  file=sys.stderr)
+    else:
+        ap.error("expected IMAGES_DIR [OAVIF_PATH] OUTPUT_CSV")
+    return args
+
+
+def main(argv=None) -> int:
+    args = parse_cli(argv)
 
     import torch
     import torch.distributed as dist
@@ -285,10 +323,19 @@ def main(argv=None) -> int:
     if not torch.cuda.is_available():
         print("oavif_amd.batch: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
         return 3
+    # One process per GPU over RCCL (backend "nccl").  OAVIF_BENCH_BACKEND=gloo is the rehearsal
+    # mode bench.py also has, for boxes with fewer GPUs than ranks: ranks share devices
+    # (local_rank modulo the device count) and the one gather runs on CPU tensors.
+    backend = os.environ.get("OAVIF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     files = list_images(args.images_dir)
     if not files:
@@ -303,11 +350,13 @@ def main(argv=None) -> int:
     tls = threading.local()
     all_scorers = []
 
-    def encode_fn(_i, path):
+    names = output_names(files)
+
+    def encode_fn(i, path):
         if not hasattr(tls, "scorer"):  # one context (HIP stream + scratch) per worker thread
             tls.scorer = Ssimu2(local_rank)
             all_scorers.append(tls.scorer)
-        return encode_image(tls.scorer, path, out_dir / f"{path.stem}.avif", args.score_tgt,
+        return encode_image(tls.scorer, path, out_dir / names[i], args.score_tgt,
                             args.tolerance, args.max_pass, args.speed)
 
     if rank == 0:
@@ -316,13 +365,13 @@ def main(argv=None) -> int:
         dist.barrier()
     t0 = time.perf_counter()
     results = run_batch(files, encode_fn, rank, world,
-                        gather_device=torch.device("cuda", local_rank) if world > 1 else None,
+                        gather_device=torch.device("cuda", local_rank) if world > 1 and backend == "nccl" else None,
                         log=lambda s: print(s, file=sys.stderr), workers=args.workers)
     wall = time.perf_counter() - t0
     if not args.keep:
         for i in shard(len(files), rank, world):
             try:
-                (out_dir / f"{files[i].stem}.avif").unlink()
+                (out_dir / names[i]).unlink()
             except OSError:
                 pass
     if rank == 0:

@@ -213,14 +213,25 @@ def print_version() -> None:
 
 # ---- image I/O (CPU; counterpart of io.zig) -------------------------------------------------------
 
-def load_image(path: str):
-    """io.loadImage + Image.toRGB8 (io.zig:57-150): -> (rgb8 (h,w,3) u8, src PIL image, channels,
-    hbd).  16-bit sources are truncated with >> 8, alpha is dropped, gray is replicated."""
+class Source:
+    """One loaded input image (io.zig's `Image`, io.zig:42-55): the pixels as decoded
+    (`pixels`: (h, w, channels) u8, what the encoder gets, alpha included), the scorer's
+    reference `rgb` ((h, w, 3) u8, Image.toRGB8), and the ICC profile to pass through."""
+    __slots__ = ("rgb", "pixels", "channels", "hbd", "icc")
+
+    def __init__(self, rgb, pixels, channels, hbd, icc):
+        self.rgb, self.pixels, self.channels, self.hbd, self.icc = rgb, pixels, channels, hbd, icc
+
+
+def load_source(path: str) -> Source:
+    """io.loadImage + Image.toRGB8 (io.zig:57-150).  16-bit sources are truncated with >> 8,
+    alpha is dropped from the scorer's reference (but kept in `pixels`), gray is replicated."""
     import numpy as np
     from PIL import Image
     ext = os.path.splitext(path)[1].lower()
     if ext not in (".jpg", ".jpeg", ".png", ".pam", ".webp", ".avif"):
         raise CliError("UnsupportedImageFormat")
+    icc = None
     if ext == ".pam":
         from .pam import load_pam
         data, w, h, ch = load_pam(open(path, "rb").read())
@@ -237,27 +248,39 @@ def load_image(path: str):
             arr = np.asarray(im)
             if arr.ndim == 2:
                 arr = arr[..., None]
+        icc = im.info.get("icc_profile")  # Image.icc (io.zig:48): handed to the encoder unchanged (io.zig:556-560)
     ch = arr.shape[2]
     if ch == 1 or ch == 2:
         rgb = np.repeat(arr[..., :1], 3, axis=2)
     else:
         rgb = arr[..., :3]
-    global _src_icc  # Image.icc (io.zig:48): handed to the encoder unchanged (io.zig:556-560)
-    _src_icc = None if ext == ".pam" else im.info.get("icc_profile")
-    return np.ascontiguousarray(rgb), arr, ch, hbd
+    return Source(np.ascontiguousarray(rgb), arr, ch, hbd, icc)
+
+
+def load_image(path: str):
+    """-> (rgb8 (h,w,3) u8, source pixels, channels, hbd); the ICC profile of the last image
+    loaded this way is what `_encode` passes through when none is given (the CLI handles one
+    image per process; the batch driver uses `load_source` and passes `icc` explicitly)."""
+    global _src_icc
+    s = load_source(path)
+    _src_icc = s.icc
+    return s.rgb, s.pixels, s.channels, s.hbd
 
 
 _src_icc = None
+_USE_CLI_ICC = object()
 
 
-def _encode(src, o: AvifEncOptions, q: int) -> bytes:
+def _encode(src, o: AvifEncOptions, q: int, icc=_USE_CLI_ICC) -> bytes:
     """io.encodeAvifToBuffer (io.zig:544-636) through Pillow: YUV444, the options of copyToEncoder."""
     import io as _io
     from PIL import Image
+    if icc is _USE_CLI_ICC:
+        icc = _src_icc
     mode = {1: "L", 2: "LA", 3: "RGB", 4: "RGBA"}[src.shape[2]]
     im = Image.fromarray(src[..., 0] if src.shape[2] == 1 else src, mode)
     buf = _io.BytesIO()
-    extra = {"icc_profile": _src_icc} if _src_icc else {}
+    extra = {"icc_profile": icc} if icc else {}
     im.save(buf, format="AVIF", quality=int(q), subsampling="4:4:4", speed=o.speed,
             max_threads=o.max_threads, **extra, tile_rows=o.tile_rows_log2, tile_cols=o.tile_cols_log2,
             autotiling=o.auto_tiling, advanced={"tune": o.tune} if o.tune == "ssim" else None)

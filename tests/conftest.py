@@ -25,6 +25,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def anchors():
+    """tests/golden/pairs_v1_anchors.json: per fixture the fp64-blur score (an anchor that shares
+    no rounding sequence with the HIP kernel) and the published-recursion scores + recorded gaps."""
+    with open(os.path.join(GOLDEN_DIR, "pairs_v1_anchors.json")) as f:
+        return {p["name"]: p for p in json.load(f)["pairs"]}
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import ssimu2_oracle
     ssimu2_oracle.build()

@@ -90,3 +90,52 @@ def test_csv_schema_matches_reference_tool(image_dir, tmp_path):
             assert "." in r[5] and len(r[5].split(".")[1]) == 2
         else:
             assert r[7] == "error" and r[2] == "" and r[6] == "" and r[8].startswith("Error processing")
+
+
+from oavif_amd import batch, synth  # noqa: E402
+
+
+def test_measure_py_positionals_are_accepted():
+    """measure.py:111-123 takes `images_dir oavif_path output_csv`; an existing invocation must
+    keep working (oavif_path is accepted and unused), and the two-positional form stays."""
+    a = batch.parse_cli(["imgs", "./oavif", "out.csv", "--tolerance", "1.5", "--keep"])
+    assert (a.images_dir, a.output_csv, a.tolerance, a.keep) == ("imgs", "out.csv", 1.5, True)
+    b = batch.parse_cli(["imgs", "out.csv"])
+    assert (b.images_dir, b.output_csv, b.tolerance, b.keep) == ("imgs", "out.csv", 2.0, False)
+    with pytest.raises(SystemExit):
+        batch.parse_cli(["imgs"])
+
+
+def test_output_names_never_collide(tmp_path):
+    files = [tmp_path / n for n in ("a.png", "a.jpg", "b.png", "c.JPEG")]
+    names = batch.output_names(files)
+    assert names == ["a_png.avif", "a_jpg.avif", "b.avif", "c.avif"]
+    assert len(set(names)) == len(names)
+
+
+def test_batch_and_cli_share_one_encode_path_and_keep_alpha(tmp_path, monkeypatch):
+    """The batch encodes what oavif encodes (io.zig:564: the RGBA source, not its RGB view): an
+    RGBA PNG keeps its alpha plane, and the bytes equal the CLI mirror's for the same quantizer."""
+    import io
+    from types import SimpleNamespace
+
+    from PIL import Image
+
+    from oavif_amd import cli, tq
+    rgb = synth.make_ref(64, 48, 3)
+    alpha = np.tile(np.linspace(0, 255, 64, dtype=np.uint8), (48, 1))
+    src = tmp_path / "x.png"
+    Image.fromarray(np.dstack([rgb, alpha]), "RGBA").save(src)
+
+    def fake_search(scorer, ref, codec, score_tgt, tolerance, max_pass):
+        assert ref.shape == (48, 64, 3)                 # the scorer's reference is RGB8 (main.zig:86)
+        dec, _size = codec(61)
+        assert dec.shape == (48, 64, 3)                 # decodeAvifToRgb drops alpha (io.zig:654-663)
+        return SimpleNamespace(q=61, score=80.5, num_pass=1, buf_q=61)
+    monkeypatch.setattr(tq, "search_hip", fake_search)
+    out = tmp_path / "x.avif"
+    q, score, passes, nbytes = batch.encode_image(None, src, out)
+    assert (q, passes, nbytes) == (61, 1, out.stat().st_size)
+    assert Image.open(io.BytesIO(out.read_bytes())).mode == "RGBA"
+    assert cli.main(["-q", "61", str(src), str(tmp_path / "cli.avif")]) == 0
+    assert (tmp_path / "cli.avif").read_bytes() == out.read_bytes()

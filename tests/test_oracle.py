@@ -269,3 +269,23 @@ def test_second_recursive_evaluation_order_is_a_different_but_close_score(oracle
         diffs.append(abs(a - b))
     assert max(diffs) > 0.0
     assert max(diffs) < 1.0
+
+
+def test_anchor_file_is_what_the_oracle_computes(oracle, golden):
+    """tests/golden/pairs_v1_anchors.json (the GPU tests' independent anchors) against the
+    oracle's fp64-blur and published-recursion modes today."""
+    import json
+    import os
+    arrays, meta = golden
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairs_v1_anchors.json")
+    anchors = {p["name"]: p for p in json.load(open(path))["pairs"]}
+    cases = [(p["name"], arrays["ref"], arrays[p["name"]], p["score_fir"]) for p in meta["pairs"]]
+    cases.append(("odd", arrays["odd_ref"], arrays["odd_dist"], meta["odd"]["score_fir"]))
+    for name, ref, dist, fir in cases:
+        a = anchors[name]
+        ex, avg, _ = oracle.compute_ssimu2(ref, dist, oracle.BLUR_EXACT, return_averages=True)
+        assert abs(ex - a["score_exact"]) < 1e-9, name
+        assert np.allclose(avg.reshape(-1), a["averages_exact"], rtol=1e-12, atol=0), name
+        assert abs(oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR) - a["score_iir"]) < 1e-9, name
+        assert abs((fir - a["score_iir"]) - a["gap_fir_minus_iir"]) < 1e-9, name
+        assert abs(fir - ex) <= 6.5e-3, name        # the envelope the GPU test leans on
