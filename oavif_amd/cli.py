@@ -312,6 +312,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         print_version()
         return 0
     own_scorer = False
+    prefetched = None
     try:
         o, inp, out = parse_args(argv)
         if scorer is None and o.quality is None and inp is not None and out is not None:
@@ -320,14 +321,17 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
             if "torch" not in sys.modules:
                 os.environ.setdefault("OAVIF_AMD_NO_TORCH", "1")  # a CLI run shares nothing with torch
             from . import _lib
-            _lib.lib().ssimu2_prefetch(int(os.environ.get("LOCAL_RANK", "0")))
+            prefetched = int(os.environ.get("LOCAL_RANK", "0"))
+            _lib.lib().ssimu2_prefetch(prefetched)
         if inp is None or out is None:
             raise CliError("MissingInputOrOutput")
         rgb, src, channels, hbd = load_image(inp)
         h, w, _ = rgb.shape
         eprint(f"Read {w}x{h}, {'RGBA' if channels > 3 else 'RGB'}, {16 if hbd else 8}-bit, "
                f"{os.path.getsize(inp)} bytes")
-        out_depth = 10 if o.tenbit else (10 if hbd else 8)
+        # The reference encodes 10-bit when --tenbit 1 or the source is 16-bit (io.zig:546-548).
+        # Pillow's libavif plugin, the stand-in codec here, writes 8-bit only: say what is written.
+        out_depth = 8
         if o.quality is not None:  # bypass the search (main.zig:93-100)
             eprint(f"Encoding [q{o.quality}, speed {o.speed}, {out_depth}-bit]")
             data = _encode(src, o, o.quality)
@@ -393,6 +397,12 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
     finally:
         if own_scorer and scorer is not None:
             scorer.close()
+        elif prefetched is not None:
+            # an early error exit (missing input, unsupported format, codec error) before any
+            # context was created: let the background HIP start-up finish before the process
+            # tears down under it
+            from . import _lib
+            _lib.lib().ssimu2_prefetch_join(prefetched)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ const Ctx = opaque {};
 
 extern fn ssimu2_ctx_create(device: c_int, hip_stream: ?*anyopaque, out_ctx: *?*Ctx) c_int;
 extern fn ssimu2_prefetch(device: c_int) c_int;
+extern fn ssimu2_prefetch_join(device: c_int) c_int;
 extern fn ssimu2_ctx_destroy(ctx: ?*Ctx) void;
 extern fn ssimu2_last_error(ctx: ?*const Ctx) [*:0]const u8;
 extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: u32, h: u32, channels: u32, out_score: *f64) c_int;
@@ -42,9 +43,11 @@ extern fn ssimu2_score_against_reference_strided(ctx: ?*Ctx, pixels: [*]const u8
 pub var device: c_int = 0;
 
 /// oavif scores every pass of a search against the same `e.rgb` slice (main.zig:86,
-/// tq.zig:37).  When true, a reference slice with the same pointer, length and dimensions
-/// as the previous call is uploaded (and its linear-light pyramid built) only once.
-/// Set to false if the caller mutates the reference buffer in place between calls.
+/// tq.zig:37).  When true, a reference slice with the same pointer, length, dimensions and
+/// content fingerprint (64 sampled bytes) as the previous call is uploaded (and its caches
+/// built) only once.  Set to false -- or call invalidateReference() -- if the caller rewrites
+/// the reference buffer in place between calls; hosts that process several images per process
+/// should call invalidateReference() when an image's `e.rgb` is freed (INTEGRATION.md 2a).
 pub var cache_reference: bool = true;
 
 var g_ctx: ?*Ctx = null;
@@ -52,6 +55,7 @@ var g_ref_ptr: ?[*]const u8 = null;
 var g_ref_len: usize = 0;
 var g_ref_w: u32 = 0;
 var g_ref_h: u32 = 0;
+var g_ref_fp: u64 = 0;
 
 fn check(rc: c_int) Error!void {
     return switch (rc) {
@@ -74,11 +78,59 @@ fn context() Error!*Ctx {
     return c.?;
 }
 
+/// A cheap content fingerprint of the reference: FNV-1a over 64 bytes sampled at 64 evenly spaced
+/// positions.  The cached reference is keyed on (pointer, length, size, fingerprint): an allocator
+/// that hands a freed `e.rgb` address to the next same-sized image no longer makes the shim score
+/// against the previous image's cached pyramid (oavif today handles one image per process, so
+/// this cannot happen yet; a multi-image host should still call invalidateReference()).
+fn fingerprint(buf: []const u8) u64 {
+    var h: u64 = 0xcbf29ce484222325;
+    if (buf.len == 0) return h;
+    const step: usize = @max(buf.len / 64, 1);
+    var i: usize = 0;
+    while (i < buf.len) : (i += step) {
+        h = (h ^ buf[i]) *% 0x100000001b3;
+    }
+    return h;
+}
+
+fn sameReference(reference: []const u8, width: u32, height: u32) bool {
+    return g_ref_ptr != null and g_ref_ptr.? == reference.ptr and g_ref_len == reference.len and
+        g_ref_w == width and g_ref_h == height and g_ref_fp == fingerprint(reference);
+}
+
+fn rememberReference(reference: []const u8, width: u32, height: u32) void {
+    g_ref_ptr = reference.ptr;
+    g_ref_len = reference.len;
+    g_ref_w = width;
+    g_ref_h = height;
+    g_ref_fp = fingerprint(reference);
+}
+
+/// Explicit control for hosts that process several images in one process: upload `reference`
+/// now (what computeSsimu2 would do on first sight of it) ...
+pub fn setReference(reference: []const u8, width: u32, height: u32) Error!void {
+    const ctx = try context();
+    try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
+    rememberReference(reference, width, height);
+}
+
+/// ... and forget it (call when `e.rgb` is freed or rewritten in place).
+pub fn invalidateReference() void {
+    g_ref_ptr = null;
+}
+
 /// Optional, for one-image runs: start the once-per-process GPU initialisation (0.15-0.35 s) on
 /// a background thread; call it first thing in main() and the cost hides behind io.loadImage and
 /// the first encode (INTEGRATION.md section 2d).
 pub fn prefetch() void {
     _ = ssimu2_prefetch(device);
+}
+
+/// Wait for a prefetch still in flight.  Call before an early exit that never reached the scorer
+/// (bad arguments, unreadable input), so HIP start-up does not race process teardown.
+pub fn prefetchJoin() void {
+    _ = ssimu2_prefetch_join(device);
 }
 
 /// Release the GPU context (optional; the process exit does it too).
@@ -106,14 +158,9 @@ pub fn computeSsimu2(
     const ctx = try context();
     var score: f64 = 0;
     if (cache_reference and channels == 3) {
-        const same = g_ref_ptr != null and g_ref_ptr.? == reference.ptr and
-            g_ref_len == reference.len and g_ref_w == width and g_ref_h == height;
-        if (!same) {
+        if (!sameReference(reference, width, height)) {
             try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
-            g_ref_ptr = reference.ptr;
-            g_ref_len = reference.len;
-            g_ref_w = width;
-            g_ref_h = height;
+            rememberReference(reference, width, height);
         }
         try check(ssimu2_score_against_reference(ctx, distorted.ptr, &score));
         return score;
@@ -139,14 +186,9 @@ pub fn computeSsimu2Decoded(
     const need: usize = @as(usize, width) * @as(usize, height) * 3;
     if (reference.len < need) return Error.InvalidArgument;
     const ctx = try context();
-    const same = g_ref_ptr != null and g_ref_ptr.? == reference.ptr and
-        g_ref_len == reference.len and g_ref_w == width and g_ref_h == height;
-    if (!same or !cache_reference) {
+    if (!cache_reference or !sameReference(reference, width, height)) {
         try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
-        g_ref_ptr = reference.ptr;
-        g_ref_len = reference.len;
-        g_ref_w = width;
-        g_ref_h = height;
+        rememberReference(reference, width, height);
     }
     var score: f64 = 0;
     try check(ssimu2_score_against_reference_strided(ctx, pixels, row_bytes, src_channels, &score));

@@ -82,7 +82,7 @@ def test_quality_bypass_writes_avif_without_gpu(tmp_path, capsys):
     assert cli.main(["-q", "60", str(src), str(out)]) == 0
     err = capsys.readouterr().err.splitlines()
     assert err[1].startswith("Read 64x48, RGB, 8-bit, ")
-    assert err[2] == "Encoding [q60, speed 9, 10-bit]"
+    assert err[2] == "Encoding [q60, speed 9, 8-bit]"   # Pillow writes 8-bit: the line says what is written
     assert err[3].startswith("Compressed to ") and err[3].endswith(" bpp)")
     assert "passes" not in "\n".join(err)          # measure.py then records passes = None
     assert synth.avif_decode(out.read_bytes()).shape == (48, 64, 3)
@@ -160,3 +160,17 @@ def test_icc_profile_passes_through_the_quality_bypass(tmp_path, capsys):
     assert cli.main(["-q", "70", str(plain), str(out)]) == 0
     capsys.readouterr()
     assert not Image.open(out).info.get("icc_profile")
+
+
+def test_early_error_exit_after_prefetch_does_not_hang(tmp_path):
+    """cli.main starts the scorer's background initialisation (ssimu2_prefetch) before it loads
+    the input; an early error exit must join it (ssimu2_prefetch_join) and return 1 promptly --
+    with or without a GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "oavif_amd.cli", str(tmp_path / "missing.png"), str(tmp_path / "o.avif")],
+                       cwd=root, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1
+    assert "error: FileNotFound" in p.stderr

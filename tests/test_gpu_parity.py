@@ -422,7 +422,7 @@ def test_cli_search_end_to_end(scorer, tmp_path, capsys):
     assert cli.main(["--score-tgt", "75", "--tolerance", "1.5", str(src), str(out)], scorer=scorer) == 0
     err = capsys.readouterr().err.splitlines()
     assert err[1].startswith("Read 320x240, RGB, 8-bit, ")
-    assert err[2] == "Searching [tgt 75±1.5, speed 9, 10-bit]"
+    assert err[2] == "Searching [tgt 75±1.5, speed 9, 8-bit]"
     m = re.fullmatch(r"Found q(\d+) \(score (-?\d+\.\d{2}), (\d+) passes\)", err[3])
     assert m, err[3]
     assert re.search(r"(\d+)\s+passes?", err[3]).group(1) == m.group(3)      # measure.py:27
