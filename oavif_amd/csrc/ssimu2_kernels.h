@@ -463,7 +463,8 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
     // have landed by then: 4.5 rows = several microseconds of flight, enough for an HBM miss
     // under load); slot j is refilled every QD rows, the loop body is unrolled QD times, so the
     // queue rotates without register moves.
-    constexpr int QD = 2 * GROUP;
+    constexpr int NG = 2;  // groups in flight (1, 3 and 4 measured the same: what mattered was the counted wait)
+    constexpr int QD = NG * GROUP;
     uint32_t raw0[QD][3], raw1[QD][3];
     float lin0[3] = {0.f, 0.f, 0.f}, lin1[3] = {0.f, 0.f, 0.f};  // LUT values of the next row to convert
     // A row outside the image (only in the halo of the image's first and last segments) loads the

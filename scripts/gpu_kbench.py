@@ -14,7 +14,7 @@ import oavif_amd  # noqa: E402
 from oavif_amd import synth  # noqa: E402
 
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-NP = 8
+NP = int(sys.argv[3]) if len(sys.argv) > 3 else 8   # distinct pairs in rotation
 ref = synth.make_ref(w, h, 0)
 dst = synth.distort(ref, "blockq", 2)
 tr = torch.from_numpy(ref).cuda().contiguous()
@@ -32,8 +32,8 @@ score = s.score_device(pr[0], pd[0], w, h)
 for _ in range(100):  # clocks
     s.enqueue_device(pr[0], pd[0], w, h)
 s.wait()
-k_rot = s.time_march_rotating(pr, pd, w, h, 64) * 1e3
-ks = [s.time_stage(pr[0], pd[0], w, h, st, 8) * 1e3 for st in range(3)]
+k_rot = min(s.time_march_rotating(pr, pd, w, h, 8 * NP) for _ in range(3)) * 1e3
+ks = [s.time_stage(pr[0], pd[0], w, h, st, 50) * 1e3 for st in range(3)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 n = 64
