@@ -42,7 +42,8 @@ int ssimu2_time_stage(ssimu2_ctx* ctx, const void* d_ref, const void* d_dist, ui
 /* The same for the dominant kernel only, rotating over `npairs` distinct device-resident pairs
    (d_refs[i], d_dists[i]; all w x h) so that the inputs of consecutive launches come from HBM,
    not from the 256 MiB Infinity Cache: launch j reads pair j % npairs.  The linear-light pyramids
-   of all pairs are built first (not timed) into scratch owned by this call. */
+   of all pairs are built first (not timed) into scratch owned by this call, and ~30 ms of the same
+   launches run untimed before the timed ones (clock settling after the idle gap of the set-up). */
 int ssimu2_time_march_rotating(ssimu2_ctx* ctx, const void* const* d_refs, const void* const* d_dists,
                                int npairs, uint32_t w, uint32_t h, int iters, float* out_ms_avg);
 

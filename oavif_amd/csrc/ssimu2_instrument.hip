@@ -187,8 +187,12 @@ int ssimu2_time_march_rotating(ssimu2_ctx* c, const void* const* d_refs, const v
     }
     float ms = 0.f;
     if (blocks > 0) {
-        for (int j = 0; j < npairs; ++j)  // untimed: first touch of every pair
-            hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, plans[j]);
+        // untimed: ~30 ms of the same launches first.  Allocating the scratch above leaves the GPU
+        // idle for a moment, and an MI355X that has been idle runs its next ~100 launches 5-15 %
+        // slower while its clocks come back up (kernel-trace of bench.py: 166 -> 154 -> 144 -> 141 us)
+        const int warm = npairs * 2 > 192 ? npairs * 2 : 192;
+        for (int j = 0; j < warm; ++j)
+            hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, plans[j % npairs]);
         e = hipEventRecord(c->ev0, c->stream);
         for (int j = 0; j < iters && e == hipSuccess; ++j)
             hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, plans[j % npairs]);
