@@ -1,5 +1,6 @@
-"""bench.py's one-line JSON contract, checked on the line recorded on the MI355X
-(profiles/r01_bench.json) and on bench.py's own constants.  CPU only."""
+"""bench.py's one-line JSON contract, checked on the newest line recorded on the MI355X
+(profiles/rNN_bench.json) and on bench.py's own constants.  CPU only."""
+import glob
 import ast
 import json
 import os
@@ -8,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")))[-1]))
 
 
 def test_required_keys_and_types():
@@ -42,6 +43,37 @@ def test_roofline_and_cpu_baseline_objects():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["quantizer_match_vs_cpu"]["identical"] is True
     assert d["cached_reference"]["bit_identical_to_pair_score"] is True
+
+
+def test_workload_is_hbm_fed_and_roofline_is_stated_honestly():
+    """the timed steps rotate over distinct pairs (> the 256 MiB Infinity Cache), the
+    cache-resident figure is only a labelled extra, north_star's blur-pyramid target sits beside
+    the W-model fraction with its verdict, and the VALU fractions carry both peaks."""
+    d = _line()
+    assert d["config"]["distinct_pairs_per_gpu"] >= 8 * d["config"]["streams_per_gpu"]
+    assert d["config"]["input_working_set_MB"] > 268.4
+    assert "cache_resident" in d and d["cache_resident"]["value"] > 0
+    r = d["roofline"]
+    assert r["blur_pyramid"]["target"] == 0.70 and r["blur_pyramid"]["met"] == (r["blur_pyramid_frac"] >= 0.70)
+    assert abs(r["blur_pyramid_frac"] - 31.99 * 3840 * 2160 / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-3
+    if "valu_roofline" in d:
+        v = d["valu_roofline"]
+        assert v["peak_nominal"] == 1.2 and abs(v["frac_nominal"] - v["achieved"] / 1.2) < 1e-3
+        assert v["frac_measured"] is None or v["frac_nominal"] < v["frac_measured"]
+
+
+def test_counters_file_is_generated_and_stamped():
+    """profiles/counters.json comes from scripts/make_counters_json.py and names the kernel
+    sources it was measured on; bench.py flags it stale when they differ."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    c = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    assert "make_counters_json.py" in c["source"] and len(c["kernel_source_hash"]) == 16
+    assert c["march_hbm_bytes_per_launch"] == int(c["march_fetch_KiB_reported"] * 2048 + c["march_write_KiB_reported"] * 1024)
+    loaded = bench.load_counters((3840, 2160))
+    assert loaded["stale"] == (c["kernel_source_hash"] != bench.kernel_source_hash())
+    assert bench.load_counters((1920, 1080)) is None
 
 
 def test_bench_byte_model_matches_survey():
