@@ -282,26 +282,30 @@ int ensure_capacity(ssimu2_ctx* c, uint32_t w, uint32_t h) {
     return SSIMU2_OK;
 }
 
-// Linear-light pyramids of up to two frames: levels 1..3 from the u8 frames in one launch,
-// levels 4..5 from level 3 in a second one.  frames[i] = u8 frame, lin[i] = its pyramid buffer.
+// Band-pyramid arguments of up to two frames: levels 1..nscales-1 of frames[i] into lin[i].
+PyrBandArgs pyramid_args(const Pyramid& p, int nframes, const uint8_t* const* frames, float* const* lin) {
+    PyrBandArgs a{};
+    a.nlevels = p.nscales > 1 ? p.nscales - 1 : 0;
+    for (int l = 0; l < p.nscales; ++l) {
+        a.w[l] = p.w[l];
+        a.h[l] = p.h[l];
+    }
+    a.nframes = nframes;
+    a.bands_x = (p.w[0] + PYR_BAND_W - 1) / PYR_BAND_W;
+    a.bands_y = (p.h[0] + PYR_BAND_H - 1) / PYR_BAND_H;
+    for (int f = 0; f < nframes; ++f) {
+        a.in[f] = frames[f];
+        for (int l = 0; l < a.nlevels; ++l) a.out[f][l] = lin[f] + p.lin_off[l + 1];
+    }
+    return a;
+}
+
+// Linear-light pyramids of up to two frames as a launch of their own (all levels, one launch).
 void launch_pyramid(ssimu2_ctx* c, const Pyramid& p, int nframes, const uint8_t* const* frames,
                     float* const* lin) {
-    for (int base = 0; base + 1 < p.nscales; base += 3) {
-        PyramidArgs a{};
-        const int n = p.nscales - 1 - base < 3 ? p.nscales - 1 - base : 3;
-        a.nlevels = n;
-        for (int k = 0; k <= n; ++k) {
-            a.w[k] = p.w[base + k];
-            a.h[k] = p.h[base + k];
-        }
-        for (int f = 0; f < nframes; ++f) {
-            a.in[f] = base == 0 ? (const void*)frames[f] : (const void*)(lin[f] + p.lin_off[base]);
-            for (int k = 0; k < n; ++k) a.out[f][k] = lin[f] + p.lin_off[base + 1 + k];
-        }
-        dim3 grid((a.w[1] + 31) / 32, (a.h[1] + PYR_TILE_H - 1) / PYR_TILE_H, nframes), block(256);
-        if (base == 0) hipLaunchKernelGGL(k_pyramid<true>, grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL(k_pyramid<false>, grid, block, 0, c->stream, a);
-    }
+    if (p.nscales < 2) return;
+    const PyrBandArgs a = pyramid_args(p, nframes, frames, lin);
+    hipLaunchKernelGGL(k_pyramid_bands, dim3(a.bands_x * a.bands_y * nframes), dim3(512), 0, c->stream, a);
 }
 
 // float offset of scale s in the cached reference XYB buffer (scale 0 first)

@@ -279,6 +279,180 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
     }
 }
 
+// ---- linear-light pyramid, all five levels from the 8-bit frame in one pass -----------------------
+// A BAND is 256 x 32 pixels of the 8-bit frame (aligned to 256 / 32, so every 2x2 source block
+// of every level, clamped or not, lies inside it: 32 = 2^5) and is worked on by 512 threads, one
+// 4 x 4 pixel block each:
+//   level 1 (2 x 2 per thread) and level 2 (1 per thread) in registers -- per thread four rows of
+//     12 contiguous bytes = three dword loads each, twelve loads in flight; a wave covers 768
+//     contiguous bytes of each of its rows;
+//   levels 3, 4, 5 (32 x 4, 16 x 2, 8 x 1 per band) through three small LDS tiles.
+// Same arithmetic, in the same order, as k_pyramid (the CPU checker's or_downsample2):
+// (((p00 + p01) + p10) + p11) * 0.25 on clamped coordinates, level by level.
+// The function is a ROLE, not a kernel: k_pyramid_bands runs it alone (set_reference, the first
+// score of a run), and the marching kernels run it in the workgroups BEHIND their own (the tail
+// of a marching launch has idle slots): the pyramid of score n+1 then costs ~4 us instead of the
+// ~27 it costs as a launch of its own or the ~24 it costs beside another stream's marching kernel
+// (where one 30-register wave per SIMD is all that fits; DESIGN.md "Two scores in flight").
+struct PyrBandArgs {
+    const uint8_t* in[2];  // frames (tight RGB8)
+    float* out[2][5];      // per frame: planes [3][h_l][w_l] of levels 1..5 (entries >= nlevels unused)
+    int w[6], h[6];        // level dimensions, [0] = the 8-bit frame
+    int nlevels;           // levels to produce: 1..5; 0 = nothing to do
+    int bands_x, bands_y, nframes;
+};
+
+constexpr int PYR_BAND_W = 256, PYR_BAND_H = 32;
+constexpr int PYR_BAND_LDS_FLOATS = 3 * 8 * 64 + 3 * 4 * 32 + 3 * 2 * 16;  // levels 2, 3, 4 tiles
+
+__device__ __forceinline__ float box4(float p00, float p01, float p10, float p11) {
+    float sum = p00;
+    sum += p01;
+    sum += p10;
+    sum += p11;
+    return sum * 0.25f;
+}
+
+// One level from an LDS tile of the level above: `src` is [3][sh][sw] (tile origin = global
+// (2*ox0, 2*oy0) of the level above, whose size is wa x ha), outputs ox0+lx, oy0+ly.
+__device__ __forceinline__ void pyr_lds_level(const float* src, int sw, int sh, int wa, int ha, float* dst_tile,
+                                              int dw_tile, int dh_tile, float* out, int wo, int ho, int ox0,
+                                              int oy0, int lx, int ly) {
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (ox < wo && oy < ho) {
+        const int xa = 2 * lx, xb = min(2 * ox + 1, wa - 1) - 2 * ox0;
+        const int ya = 2 * ly, yb = min(2 * oy + 1, ha - 1) - 2 * oy0;
+        const size_t n = (size_t)wo * ho;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = src + c * sw * sh;
+            v[c] = box4(p[ya * sw + xa], p[ya * sw + xb], p[yb * sw + xa], p[yb * sw + xb]);
+            out[c * n + (size_t)oy * wo + ox] = v[c];
+        }
+    }
+    if (dst_tile) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst_tile[(c * dh_tile + ly) * dw_tile + lx] = v[c];
+    }
+}
+
+// `lut`: the sRGB table in LDS; `lds`: PYR_BAND_LDS_FLOATS floats of scratch; 512 threads, all of
+// which must call (barriers inside).  `band` < bands_x * bands_y * nframes.
+__device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, const float* lut, float* lds) {
+    const int t = threadIdx.x;
+    const int per_frame = a.bands_x * a.bands_y;
+    const int f = band / per_frame;
+    const int r = band - f * per_frame;
+    const int by = r / a.bands_x, bx = r - by * a.bands_x;
+    const int w0 = a.w[0], h0 = a.h[0], w1 = a.w[1], h1 = a.h[1];
+    float* s2 = lds;                       // [3][8][64]
+    float* s3 = s2 + 3 * 8 * 64;           // [3][4][32]
+    float* s4 = s3 + 3 * 4 * 32;           // [3][2][16]
+    const int tx = t & 63, ty = t >> 6;
+    const int X0 = bx * PYR_BAND_W + 4 * tx, Y0 = by * PYR_BAND_H + 4 * ty;
+    // ---- levels 1 and 2 in registers
+    float l1[2][2][3];  // [row][col][channel] of this thread's 2 x 2 level-1 outputs
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) l1[j][i][c] = 0.f;
+    if (X0 < w0 && Y0 < h0) {
+        const uint8_t* base = a.in[f];
+        uint32_t raw[4][3];
+        const bool inside = X0 + 3 < w0 && Y0 + 3 < h0;
+        if (inside) {  // four rows of 12 contiguous bytes
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint8_t* p = base + ((size_t)(Y0 + j) * w0 + X0) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) __builtin_memcpy(&raw[j][k], p + 4 * k, 4);
+            }
+        } else {  // frame border: clamped coordinates, byte by byte
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = min(Y0 + j, h0 - 1);
+                uint8_t b[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint8_t* p = base + ((size_t)y * w0 + min(X0 + i, w0 - 1)) * 3;
+                    b[3 * i] = p[0];
+                    b[3 * i + 1] = p[1];
+                    b[3 * i + 2] = p[2];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    raw[j][k] = (uint32_t)b[4 * k] | ((uint32_t)b[4 * k + 1] << 8) | ((uint32_t)b[4 * k + 2] << 16) |
+                                ((uint32_t)b[4 * k + 3] << 24);
+            }
+        }
+        // byte 3*i + c of a row = channel c of pixel i
+#define PYR_LIN(j, i, c) lut[(raw[j][(3 * (i) + (c)) >> 2] >> (8 * ((3 * (i) + (c)) & 3))) & 255u]
+        const size_t n1 = (size_t)w1 * h1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ox = (X0 >> 1) + i, oy = (Y0 >> 1) + j;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    l1[j][i][c] = box4(PYR_LIN(2 * j, 2 * i, c), PYR_LIN(2 * j, 2 * i + 1, c),
+                                       PYR_LIN(2 * j + 1, 2 * i, c), PYR_LIN(2 * j + 1, 2 * i + 1, c));
+                if (ox < w1 && oy < h1) {
+                    float* o = a.out[f][0];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = l1[j][i][c];
+                }
+            }
+        }
+#undef PYR_LIN
+    }
+    if (a.nlevels < 2) return;
+    {
+        const int w2 = a.w[2], h2 = a.h[2];
+        const int ox = X0 >> 2, oy = Y0 >> 2;  // = 64 bx + tx, 8 by + ty
+        float v[3] = {0.f, 0.f, 0.f};
+        if (ox < w2 && oy < h2) {
+            // the level-1 column / row 2*ox+1, 2*oy+1 may not exist: the published clamp repeats the last one
+            const int ib = min(2 * ox + 1, w1 - 1) - 2 * ox, jb = min(2 * oy + 1, h1 - 1) - 2 * oy;
+            const size_t n2 = (size_t)w2 * h2;
+            float* o = a.out[f][1];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p01 = ib ? l1[0][1][c] : l1[0][0][c];
+                const float p10 = jb ? l1[1][0][c] : l1[0][0][c];
+                const float p11 = jb ? (ib ? l1[1][1][c] : l1[1][0][c]) : (ib ? l1[0][1][c] : l1[0][0][c]);
+                v[c] = box4(l1[0][0][c], p01, p10, p11);
+                o[c * n2 + (size_t)oy * w2 + ox] = v[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s2[(c * 8 + ty) * 64 + tx] = v[c];
+    }
+    if (a.nlevels < 3) return;
+    __syncthreads();
+    if (t < 128)
+        pyr_lds_level(s2, 64, 8, a.w[2], a.h[2], s3, 32, 4, a.out[f][2], a.w[3], a.h[3], bx * 32, by * 4, t & 31, t >> 5);
+    if (a.nlevels < 4) return;
+    __syncthreads();
+    if (t < 32)
+        pyr_lds_level(s3, 32, 4, a.w[3], a.h[3], s4, 16, 2, a.out[f][3], a.w[4], a.h[4], bx * 16, by * 2, t & 15, t >> 4);
+    if (a.nlevels < 5) return;
+    __syncthreads();
+    if (t < 8)
+        pyr_lds_level(s4, 16, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * 8, by, t, 0);
+}
+
+__global__ __launch_bounds__(512) void k_pyramid_bands(PyrBandArgs a) {
+    __shared__ float s_lut[256];
+    __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = c_k.lut[threadIdx.x];
+    __syncthreads();
+    pyramid_band(a, (int)blockIdx.x, s_lut, s_tiles);
+}
+
 // ---- fused per-scale kernel, marching form, all scales in one launch ----------------------------
 // One workgroup (8 waves) owns a strip of MW output columns of ONE scale and marches down
 // `seg` output rows, one image row per step.
