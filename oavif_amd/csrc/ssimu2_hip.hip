@@ -12,7 +12,7 @@
 //   partials    : fp64 [scale][18 stats][workgroups] partial sums
 //   result      : fp64 [108 averages][score][nscales], mirrored in pinned host memory
 //
-// One score = 1-2 k_pyramid launches, ONE k_march launch covering all six scales, one
+// One score = ONE k_pyramid_bands launch (all five levels), ONE k_march launch covering all six scales, one
 // k_finalize launch, one 880-byte D2H copy; everything on the ctx stream, no host sync
 // inside (enqueue / wait split).
 #include <hip/hip_runtime.h>

@@ -1,11 +1,11 @@
 // Device code of the MI355X (gfx950) SSIMULACRA2 scorer: included only by ssimu2_hip.hip.
 //
 // Kernels (wave64; VALU + LDS work, no MFMA: stencil and pointwise arithmetic):
-//   k_pyramid    : linear-light 2x2 box pyramid, up to three levels per launch from one read
-//                  of the input level (u8 sRGB frames through the LUT, or fp32 planes)
+//   k_pyramid_bands : linear-light 2x2 box pyramid, all five levels in one launch from one read
+//                  of the u8 sRGB frames (through the LUT)
 //   k_march      : ONE launch for all scales: per workgroup, a strip of 120 output columns of
 //                  one scale is marched top to bottom: sRGB LUT -> opsin -> cbrt -> positive
-//                  XYB (converter waves, LDS ring of raw rows), horizontal 9-tap of
+//                  XYB (converter waves, LDS ring of (ref, dist) pair rows), horizontal 9-tap of
 //                  {x, y, xx, yy, xy} in registers, vertical 9-tap from a 9-row register
 //                  window, SSIM + edge-difference maps, fp64 partial sums
 //   k_finalize   : fixed-order fp64 reduction of the partials, 108 averages, weighted sum,
@@ -155,130 +155,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// ---- linear-light pyramid ----------------------------------------------------------------------
-// out(ox,oy) = (((p00 + p01) + p10) + p11) * 0.25 with coordinates clamped to the last
-// row/column of the level above (the published Downsample(in, 2, 2)).  One workgroup reads a
-// 64x32 tile of the input level once and emits the 32x16, 16x8 and 8x4 tiles of the next
-// three levels (tiles are aligned to powers of two, so every 2x2 source block, clamped or
-// not, lies inside the tile).  blockIdx.z selects the frame.
-// A workgroup covers 32 x 16 outputs of the first produced level (9 KB of LDS, <= 32 VGPRs):
-// small enough to be co-resident with three k_march workgroups on a CU (3 x 49.3 KB of the
-// 160 KB LDS, 480 of 512 VGPRs per SIMD), so that with two streams the HBM-bound pyramid of one
-// score really runs under the VALU-bound marching kernel of another.
-struct PyramidArgs {
-    const void* in[2];   // per frame: u8 interleaved RGB (level 0) or fp32 planes [3][h][w]
-    float* out[2][3];    // per frame, per produced level: fp32 planes; null = not produced
-    int w[4], h[4];      // w[0],h[0] = input level; w[k],h[k] = k-th produced level
-    int nlevels;         // 1..3 levels to produce
-};
-
-constexpr int PYR_TILE_H = 16;  // rows of the first produced level per workgroup (multiple of 8)
-
-template <bool kU8>
-__global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
-    __shared__ float s1[3][PYR_TILE_H][33];
-    __shared__ float s2[3][PYR_TILE_H / 2][17];
-    __shared__ float s_lut[256];
-    const int tid = threadIdx.x;
-    const int f = blockIdx.z;
-    if (kU8) s_lut[tid] = c_k.lut[tid];
-    if (kU8) __syncthreads();
-    const int w0 = a.w[0], h0 = a.h[0], w1 = a.w[1], h1 = a.h[1];
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * PYR_TILE_H;  // tile origin at level +1
-    const size_t n0 = (size_t)w0 * h0, n1 = (size_t)w1 * h1;
-    // level +1: 32 x PYR_TILE_H outputs, PYR_TILE_H / 8 per thread
-#pragma unroll
-    for (int j = 0; j < PYR_TILE_H / 8; ++j) {
-        const int lx = tid & 31, ly = (tid >> 5) + 8 * j;
-        const int ox = tx0 + lx, oy = ty0 + ly;
-        float v[3] = {0.f, 0.f, 0.f};
-        if (ox < w1 && oy < h1) {
-            const int xa = 2 * ox, xb = min(2 * ox + 1, w0 - 1);
-            const int ya = 2 * oy, yb = min(2 * oy + 1, h0 - 1);
-            if (kU8) {
-                const uint8_t* base = (const uint8_t*)a.in[f];
-                const uint8_t* p00 = base + ((size_t)ya * w0 + xa) * 3;
-                const uint8_t* p01 = base + ((size_t)ya * w0 + xb) * 3;
-                const uint8_t* p10 = base + ((size_t)yb * w0 + xa) * 3;
-                const uint8_t* p11 = base + ((size_t)yb * w0 + xb) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float sum = s_lut[p00[c]];
-                    sum += s_lut[p01[c]];
-                    sum += s_lut[p10[c]];
-                    sum += s_lut[p11[c]];
-                    v[c] = sum * 0.25f;
-                }
-            } else {
-                const float* base = (const float*)a.in[f];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* p = base + c * n0;
-                    float sum = p[(size_t)ya * w0 + xa];
-                    sum += p[(size_t)ya * w0 + xb];
-                    sum += p[(size_t)yb * w0 + xa];
-                    sum += p[(size_t)yb * w0 + xb];
-                    v[c] = sum * 0.25f;
-                }
-            }
-            float* o = a.out[f][0];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = v[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s1[c][ly][lx] = v[c];
-    }
-    if (a.nlevels < 2) return;
-    __syncthreads();
-    // level +2: 16 x PYR_TILE_H/2 outputs, one per thread
-    const int w2 = a.w[2], h2 = a.h[2];
-    if (tid < 16 * (PYR_TILE_H / 2)) {
-        const int lx = tid & 15, ly = tid >> 4;
-        const int ox = (tx0 >> 1) + lx, oy = (ty0 >> 1) + ly;
-        float v[3] = {0.f, 0.f, 0.f};
-        if (ox < w2 && oy < h2) {
-            // local coordinates inside s1; the clamp is against the level +1 image size
-            const int xa = 2 * lx, xb = min(2 * ox + 1, w1 - 1) - tx0;
-            const int ya = 2 * ly, yb = min(2 * oy + 1, h1 - 1) - ty0;
-            const size_t n2 = (size_t)w2 * h2;
-            float* o = a.out[f][1];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sum = s1[c][ya][xa];
-                sum += s1[c][ya][xb];
-                sum += s1[c][yb][xa];
-                sum += s1[c][yb][xb];
-                v[c] = sum * 0.25f;
-                o[c * n2 + (size_t)oy * w2 + ox] = v[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s2[c][ly][lx] = v[c];
-    }
-    if (a.nlevels < 3) return;
-    __syncthreads();
-    // level +3: 8 x PYR_TILE_H/4 outputs
-    if (tid < 8 * (PYR_TILE_H / 4)) {
-        const int w3 = a.w[3], h3 = a.h[3];
-        const int lx = tid & 7, ly = tid >> 3;
-        const int ox = (tx0 >> 2) + lx, oy = (ty0 >> 2) + ly;
-        if (ox < w3 && oy < h3) {
-            const int xa = 2 * lx, xb = min(2 * ox + 1, w2 - 1) - (tx0 >> 1);
-            const int ya = 2 * ly, yb = min(2 * oy + 1, h2 - 1) - (ty0 >> 1);
-            const size_t n3 = (size_t)w3 * h3;
-            float* o = a.out[f][2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sum = s2[c][ya][xa];
-                sum += s2[c][ya][xb];
-                sum += s2[c][yb][xa];
-                sum += s2[c][yb][xb];
-                o[c * n3 + (size_t)oy * w3 + ox] = sum * 0.25f;
-            }
-        }
-    }
-}
-
 // ---- linear-light pyramid, all five levels from the 8-bit frame in one pass -----------------------
 // A BAND is 256 x 32 pixels of the 8-bit frame (aligned to 256 / 32, so every 2x2 source block
 // of every level, clamped or not, lies inside it: 32 = 2^5) and is worked on by 512 threads, one
@@ -287,13 +163,10 @@ __global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
 //     12 contiguous bytes = three dword loads each, twelve loads in flight; a wave covers 768
 //     contiguous bytes of each of its rows;
 //   levels 3, 4, 5 (32 x 4, 16 x 2, 8 x 1 per band) through three small LDS tiles.
-// Same arithmetic, in the same order, as k_pyramid (the CPU checker's or_downsample2):
-// (((p00 + p01) + p10) + p11) * 0.25 on clamped coordinates, level by level.
-// The function is a ROLE, not a kernel: k_pyramid_bands runs it alone (set_reference, the first
-// score of a run), and the marching kernels run it in the workgroups BEHIND their own (the tail
-// of a marching launch has idle slots): the pyramid of score n+1 then costs ~4 us instead of the
-// ~27 it costs as a launch of its own or the ~24 it costs beside another stream's marching kernel
-// (where one 30-register wave per SIMD is all that fits; DESIGN.md "Two scores in flight").
+// out(ox,oy) = (((p00 + p01) + p10) + p11) * 0.25 with coordinates clamped to the last row /
+// column of the level above (the published Downsample(in, 2, 2); the CPU checker's
+// or_downsample2), level by level: the same operations in the same order as round 1's
+// three-levels-per-launch kernel, whose planes these reproduce bit for bit.
 struct PyrBandArgs {
     const uint8_t* in[2];  // frames (tight RGB8)
     float* out[2][5];      // per frame: planes [3][h_l][w_l] of levels 1..5 (entries >= nlevels unused)
