@@ -305,7 +305,7 @@ void launch_pyramid(ssimu2_ctx* c, const Pyramid& p, int nframes, const uint8_t*
                     float* const* lin) {
     if (p.nscales < 2) return;
     const PyrBandArgs a = pyramid_args(p, nframes, frames, lin);
-    hipLaunchKernelGGL(k_pyramid_bands, dim3(a.bands_x * a.bands_y * nframes), dim3(512), 0, c->stream, a);
+    hipLaunchKernelGGL(k_pyramid_bands, dim3(a.bands_x * a.bands_y * nframes), dim3(PYR_THREADS), 0, c->stream, a);
 }
 
 // float offset of scale s in the cached reference XYB buffer (scale 0 first)

@@ -175,8 +175,13 @@ struct PyrBandArgs {
     int bands_x, bands_y, nframes;
 };
 
-constexpr int PYR_BAND_W = 256, PYR_BAND_H = 32;
-constexpr int PYR_BAND_LDS_FLOATS = 3 * 8 * 64 + 3 * 4 * 32 + 3 * 2 * 16;  // levels 2, 3, 4 tiles
+#ifndef EXP_PYR_THREADS
+#define EXP_PYR_THREADS 512
+#endif
+constexpr int PYR_THREADS = EXP_PYR_THREADS;          // 512 or 256
+constexpr int PYR_TX = PYR_THREADS / 8;               // threads across a band (8 thread rows of 4 pixel rows)
+constexpr int PYR_BAND_W = 4 * PYR_TX, PYR_BAND_H = 32;
+constexpr int PYR_BAND_LDS_FLOATS = 3 * 8 * PYR_TX + 3 * 4 * (PYR_TX / 2) + 3 * 2 * (PYR_TX / 4);  // levels 2, 3, 4 tiles
 
 __device__ __forceinline__ float box4(float p00, float p01, float p10, float p11) {
     float sum = p00;
@@ -219,10 +224,11 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
     const int r = band - f * per_frame;
     const int by = r / a.bands_x, bx = r - by * a.bands_x;
     const int w0 = a.w[0], h0 = a.h[0], w1 = a.w[1], h1 = a.h[1];
-    float* s2 = lds;                       // [3][8][64]
-    float* s3 = s2 + 3 * 8 * 64;           // [3][4][32]
-    float* s4 = s3 + 3 * 4 * 32;           // [3][2][16]
-    const int tx = t & 63, ty = t >> 6;
+    constexpr int TX = PYR_TX;
+    float* s2 = lds;                       // [3][8][TX]
+    float* s3 = s2 + 3 * 8 * TX;           // [3][4][TX/2]
+    float* s4 = s3 + 3 * 4 * (TX / 2);     // [3][2][TX/4]
+    const int tx = t % TX, ty = t / TX;
     const int X0 = bx * PYR_BAND_W + 4 * tx, Y0 = by * PYR_BAND_H + 4 * ty;
     // ---- levels 1 and 2 in registers
     float l1[2][2][3];  // [row][col][channel] of this thread's 2 x 2 level-1 outputs
@@ -302,23 +308,28 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s2[(c * 8 + ty) * 64 + tx] = v[c];
+        for (int c = 0; c < 3; ++c) s2[(c * 8 + ty) * TX + tx] = v[c];
     }
     if (a.nlevels < 3) return;
     __syncthreads();
-    if (t < 128)
-        pyr_lds_level(s2, 64, 8, a.w[2], a.h[2], s3, 32, 4, a.out[f][2], a.w[3], a.h[3], bx * 32, by * 4, t & 31, t >> 5);
+    if (t < 4 * (TX / 2))
+        pyr_lds_level(s2, TX, 8, a.w[2], a.h[2], s3, TX / 2, 4, a.out[f][2], a.w[3], a.h[3], bx * (TX / 2), by * 4,
+                      t % (TX / 2), t / (TX / 2));
     if (a.nlevels < 4) return;
     __syncthreads();
-    if (t < 32)
-        pyr_lds_level(s3, 32, 4, a.w[3], a.h[3], s4, 16, 2, a.out[f][3], a.w[4], a.h[4], bx * 16, by * 2, t & 15, t >> 4);
+    if (t < 2 * (TX / 4))
+        pyr_lds_level(s3, TX / 2, 4, a.w[3], a.h[3], s4, TX / 4, 2, a.out[f][3], a.w[4], a.h[4], bx * (TX / 4), by * 2,
+                      t % (TX / 4), t / (TX / 4));
     if (a.nlevels < 5) return;
     __syncthreads();
-    if (t < 8)
-        pyr_lds_level(s4, 16, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * 8, by, t, 0);
+    if (t < TX / 8)
+        pyr_lds_level(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * (TX / 8), by, t, 0);
 }
 
-__global__ __launch_bounds__(512) void k_pyramid_bands(PyrBandArgs a) {
+#ifdef EXP_PYR_VGPR
+__attribute__((amdgpu_num_vgpr(EXP_PYR_VGPR)))
+#endif
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands(PyrBandArgs a) {
     __shared__ float s_lut[256];
     __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
     if (threadIdx.x < 256) s_lut[threadIdx.x] = c_k.lut[threadIdx.x];

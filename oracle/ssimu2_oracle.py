@@ -24,6 +24,20 @@ BLUR_IIR_FMA = 3  # BLUR_IIR with the recursion's multiply-subtract fused: a sec
 _libs: dict[bool, ctypes.CDLL] = {}
 
 
+def _host_has_avx2_fma() -> bool:
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return " avx2" in flags and " fma" in flags
+
+
+def omp_build_name() -> str:
+    """Which OpenMP build `omp=True` uses: the AVX2 + FMA build of the same source when the host
+    has both (same arithmetic: explicit fmaf only), else the portable one."""
+    return "libssimu2_oracle_fast.so" if _host_has_avx2_fma() else "libssimu2_oracle_omp.so"
+
+
 def build() -> None:
     """Compile the oracle (both the scalar and the OpenMP build)."""
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -31,7 +45,7 @@ def build() -> None:
 
 def _lib(omp: bool = False) -> ctypes.CDLL:
     if omp not in _libs:
-        name = "libssimu2_oracle_omp.so" if omp else "libssimu2_oracle.so"
+        name = omp_build_name() if omp else "libssimu2_oracle.so"
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
