@@ -175,10 +175,7 @@ struct PyrBandArgs {
     int bands_x, bands_y, nframes;
 };
 
-#ifndef EXP_PYR_THREADS
-#define EXP_PYR_THREADS 512
-#endif
-constexpr int PYR_THREADS = EXP_PYR_THREADS;          // 512 or 256
+constexpr int PYR_THREADS = 512;                      // (256-thread bands of 128 pixels measured the same)
 constexpr int PYR_TX = PYR_THREADS / 8;               // threads across a band (8 thread rows of 4 pixel rows)
 constexpr int PYR_BAND_W = 4 * PYR_TX, PYR_BAND_H = 32;
 constexpr int PYR_BAND_LDS_FLOATS = 3 * 8 * PYR_TX + 3 * 4 * (PYR_TX / 2) + 3 * 2 * (PYR_TX / 4);  // levels 2, 3, 4 tiles
@@ -326,9 +323,6 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
         pyr_lds_level(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * (TX / 8), by, t, 0);
 }
 
-#ifdef EXP_PYR_VGPR
-__attribute__((amdgpu_num_vgpr(EXP_PYR_VGPR)))
-#endif
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands(PyrBandArgs a) {
     __shared__ float s_lut[256];
     __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
