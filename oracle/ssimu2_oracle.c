@@ -60,6 +60,11 @@
                              target of libjxl's MulAdd evaluates): a second, equally legitimate
                              fp32 evaluation order, kept only to measure how far two recursive
                              implementations differ from EACH OTHER (tests/tools/) */
+#define OR_BLUR_FIR_PRODFIRST 4 /* OR_BLUR_FIR with the product planes x*x, y*y, x*y rounded to fp32
+                                   FIRST and then blurred like any plane -- the published order of
+                                   operations (multiply, then blur) with the FIR in place of the
+                                   recursion.  Measures what fusing the products into the pair sums
+                                   (OR_BLUR_FIR, the kernels' contract) moves: tests/test_oracle.py */
 #define OR_BLUR_EXACT 2 /* the same 9-tap operator accumulated in fp64, result rounded to fp32:
                           what both fp32 forms approximate (evidence for DESIGN.md 2.1) */
 
@@ -350,11 +355,11 @@ static void blur_plane(const or_gauss* rg, int mode, const float* in, size_t w, 
 
 static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const float* b, size_t w,
                             size_t h, float* prod_tmp, float* tmp, float* out) {
-    if (mode == OR_BLUR_IIR || mode == OR_BLUR_IIR_FMA) {
+    if (mode == OR_BLUR_IIR || mode == OR_BLUR_IIR_FMA || mode == OR_BLUR_FIR_PRODFIRST) {
         const size_t n = w * h;
 #pragma omp parallel for schedule(static)
         for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) prod_tmp[i] = a[i] * b[i];
-        blur_plane(rg, mode, prod_tmp, w, h, tmp, out);
+        blur_plane(rg, mode == OR_BLUR_FIR_PRODFIRST ? OR_BLUR_FIR : mode, prod_tmp, w, h, tmp, out);
         return;
     }
 #pragma omp parallel for schedule(static)
@@ -649,8 +654,9 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
             blur_plane_prod(&rg, blur_mode, a, a, cw, ch, m, tmp, s11 + c * n);
             blur_plane_prod(&rg, blur_mode, b, b, cw, ch, m, tmp, s22 + c * n);
             blur_plane_prod(&rg, blur_mode, a, b, cw, ch, m, tmp, s12 + c * n);
-            blur_plane(&rg, blur_mode, a, cw, ch, tmp, mu1 + c * n);
-            blur_plane(&rg, blur_mode, b, cw, ch, tmp, mu2 + c * n);
+            const int plain_mode = blur_mode == OR_BLUR_FIR_PRODFIRST ? OR_BLUR_FIR : blur_mode;
+            blur_plane(&rg, plain_mode, a, cw, ch, tmp, mu1 + c * n);
+            blur_plane(&rg, plain_mode, b, cw, ch, tmp, mu2 + c * n);
         }
         ssim_map(mu1, mu2, s11, s22, s12, n, avg + scale * 18);
         edge_diff_map(img1, mu1, img2, mu2, n, avg + scale * 18 + 6);

@@ -20,6 +20,7 @@ BLUR_IIR = 0  # libjxl recursive Gaussian, as published
 BLUR_FIR = 1  # its exact-arithmetic equivalent, 9-tap zero-padded FIR
 BLUR_EXACT = 2  # the same operator accumulated in fp64 (what both fp32 forms approximate)
 BLUR_IIR_FMA = 3  # BLUR_IIR with the recursion's multiply-subtract fused: a second fp32 evaluation order
+BLUR_FIR_PRODFIRST = 4  # BLUR_FIR with x*x, y*y, x*y rounded first, then blurred: the published order of operations
 
 _libs: dict[bool, ctypes.CDLL] = {}
 
