@@ -529,7 +529,7 @@ def main() -> int:
             tc = time.perf_counter()
             reps = 0
             cpu_score = None
-            while reps < 3 and (time.perf_counter() - tc) < 20.0:
+            while reps < 40 and (time.perf_counter() - tc) < 15.0:
                 cpu_score = orc.compute_ssimu2(ref, dst, orc.BLUR_FIR, omp=True)
                 reps += 1
             dt = (time.perf_counter() - tc) / reps
@@ -541,8 +541,8 @@ def main() -> int:
             out["cpu_baseline"] = {
                 "value": round(mp / dt, 3), "unit": "MP/s", "cores": cores, "kind": "port",
                 "sample": f"{reps} x the same {w}x{h} pair, oracle/ssimu2_oracle.c (FIR, "
-                          f"OpenMP, {cores} threads); not the reference's Zig+fssimu2 "
-                          f"(unbuildable here)",
+                          f"OpenMP, {cores} threads, build {orc.omp_build_name()}); not the "
+                          f"reference's Zig+fssimu2 (unbuildable here)",
                 "single_thread_value": round((w // 2) * (h // 2) / 1e6 / dt1, 3),
                 "single_thread_sample": f"1 x {w // 2}x{h // 2} crop, 1 thread",
                 "score_abs_diff_vs_hip": abs(cpu_score - scores[0])}
