@@ -15,7 +15,7 @@ timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "ben
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations with the scores of one stream never overlapping (two streams stretch them)
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 64 --warmup 16 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 512 --warmup 64 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
 cd $GRAFT_REPO_ROOT
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cut -c1-150 $OUT/kernel_stats.csv
