@@ -28,6 +28,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
 
 #define OAVIF_TQ_MAX_PASS 12 /* parse_args.zig:104 */
 
@@ -139,6 +142,9 @@ void oavif_prescale_8_to_10(const uint8_t* src, size_t n, uint16_t* dst);   /* (
 void oavif_prescale_16_to_10(const uint16_t* src, size_t n, uint16_t* dst); /* v >> 6            io.zig:587 */
 void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v >> 8            io.zig:602 */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

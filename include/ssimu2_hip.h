@@ -29,6 +29,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
 
 typedef struct ssimu2_ctx ssimu2_ctx;
 
@@ -130,6 +133,9 @@ int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_
 /* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v4 (...)". */
 const char* ssimu2_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
 
 /* Parity hook: download one intermediate plane set of the last score / reference.
    `what`: SSIMU2_DEBUG_LIN_REF / _LIN_DIST = linear-light pyramid level `scale` (1..5) of the
@@ -60,6 +63,9 @@ int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double*
 int ssimu2_instr_set_segment_rows(ssimu2_ctx* ctx, int rows_scale0, int rows_other_scales);
 int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

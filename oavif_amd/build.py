@@ -52,6 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                    "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
                    "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
+                   "-fvisibility=hidden", "-fvisibility-inlines-hidden",  # exports = the headers' functions
                    "-Wall", "-Wno-unused-function", "-o", tmp]
             cmd += [os.path.join(CSRC, s) for s in sources]
             if verbose:

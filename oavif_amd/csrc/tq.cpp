@@ -211,7 +211,7 @@ struct Sim {
     int32_t next;
 };
 
-int sim_probe(void* p, uint32_t q, double* out_score) {
+static int sim_probe(void* p, uint32_t q, double* out_score) {
     Sim* m = (Sim*)p;
     if (q <= 100 && m->s->known[q]) {
         *out_score = m->s->score[q];
@@ -228,7 +228,7 @@ int sim_probe(void* p, uint32_t q, double* out_score) {
 // Score the search may see at `q`: between two probed quantizers, the line through them;
 // otherwise the model behind the first guess (tq.zig:41 inverted: score = ln(q / 6.83) / 0.0282)
 // shifted to pass through the nearest probe.
-double estimate_score(const Spec& s, uint32_t q) {
+static double estimate_score(const Spec& s, uint32_t q) {
     int below = -1, above = -1;
     for (int k = (int)q - 1; k >= 0 && below < 0; --k)
         if (s.known[k]) below = k;
@@ -246,7 +246,7 @@ double estimate_score(const Spec& s, uint32_t q) {
 
 // Candidates for the pass after `q_miss`: what the search would ask for next if q_miss scored
 // est +- (tolerance + 0.5 + k), k = 0, 1, 2, ...  (inside the tolerance the search ends).
-void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n) {
+static void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n) {
     const double est = estimate_score(s, q_miss);
     for (int k = 0; k < 24 && *n < s.fanout; ++k) {
         for (int sign = +1; sign >= -1 && *n < s.fanout; sign -= 2) {
@@ -267,7 +267,7 @@ void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n)
     }
 }
 
-int replay_probe(void* p, uint32_t q, double* out_score) {
+static int replay_probe(void* p, uint32_t q, double* out_score) {
     Spec* s = (Spec*)p;
     if (q > 100) return SSIMU2_ERR_INVALID_ARG;  // unreachable: every proposal is clamped to 0..100
     if (s->known[q]) {
@@ -300,7 +300,7 @@ struct HipPass {
     size_t last_size;
 };
 
-int hip_probe(void* p, uint32_t q, double* out_score) {
+static int hip_probe(void* p, uint32_t q, double* out_score) {
     HipPass* s = (HipPass*)p;
     size_t sz = 0;
     const int rc = s->codec(s->user, q, s->decoded, &sz);  // tq.zig:24,26 (CPU, unchanged)

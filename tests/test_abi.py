@@ -46,6 +46,10 @@ def test_product_library_exports_exactly_the_public_headers(hip_lib):
     assert got == public, got ^ public
     instr = {s for s in _exported(_lib.INSTR_LIB_PATH) if s.startswith(("ssimu2_", "oavif_"))}
     assert instr == public | set(_lib.INSTR_SYMBOLS), instr ^ (public | set(_lib.INSTR_SYMBOLS))
+    # built with -fvisibility=hidden: no helper leaks into the host's C namespace (what remains
+    # besides the API are mangled C++ names: hipcc's kernel handles and libstdc++ vague linkage)
+    plain = {s for s in _exported(_lib.LIB_PATH) if not s.startswith(("_Z", "__hip", "_init", "_fini"))}
+    assert plain == public, plain ^ public
 
 
 def test_zig_shim_and_integration_bind_only_public_symbols():
