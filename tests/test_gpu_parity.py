@@ -487,6 +487,26 @@ def test_intermediate_planes_are_bit_identical(iscorer, oracle, w, h):
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), s
 
 
+def test_every_rgb8_colour_converts_bit_identically(iscorer, scorer, oracle):
+    """All 2^24 8-bit colours, once each (4096 x 4096): the device's sRGB table, opsin mix,
+    cube root and positive-XYB offsets give the oracle's bits for EVERY input the scorer can be
+    handed at full resolution (the planes of k_ref_xyb, which shares its device functions with
+    the marching kernel's converter waves), and the colour cube scored against a noisy copy
+    goes through the marching converter itself."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    ref = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    del v
+    iscorer.set_reference(ref)
+    got = iscorer.debug_download(2, 0, 4096, 4096)
+    lin = np.ascontiguousarray(oracle.srgb_lut()[ref].transpose(2, 0, 1))
+    exp = oracle.linear_to_xyb(lin)
+    del lin
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    del got, exp
+    dist = synth.distort(ref, "noise", 1, seed=5)
+    assert abs(scorer.compute_ssimu2(ref, dist) - oracle.compute_ssimu2(ref, dist, oracle.BLUR_FIR)) <= TOL_SCORE
+
+
 def test_caller_owned_stream(hip_lib):
     """ssimu2_ctx_create(device, hipStream_t): all work goes on the caller's stream."""
     import torch
