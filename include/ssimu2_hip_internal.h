@@ -21,9 +21,11 @@ extern "C" {
 /* Parity hook: download one intermediate plane set of the last score / reference.
    `what`: SSIMU2_DEBUG_LIN_REF / _LIN_DIST = linear-light pyramid level `scale` (1..5) of the
    reference / distorted frame, SSIMU2_DEBUG_XYB_REF = cached positive-XYB planes of the
-   reference at `scale` (0..5; needs ssimu2_set_reference).  `out` receives 3 planes of
-   w_s*h_s floats; returns SSIMU2_ERR_INVALID_ARG if that level does not exist. */
-enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2 };
+   reference at `scale` (0..5; needs ssimu2_set_reference), SSIMU2_DEBUG_REF_BLUR = the cached
+   blur(ref*ref) planes of that reference (written by the marching body in emit mode: the blur
+   waves' arithmetic, downloadable).  `out` receives 3 planes of w_s*h_s floats; returns
+   SSIMU2_ERR_INVALID_ARG if that level does not exist. */
+enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2, SSIMU2_DEBUG_REF_BLUR = 3 };
 int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
                           uint32_t* out_w, uint32_t* out_h);
 

@@ -76,6 +76,10 @@ int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32
         if (scale < 0 || scale >= p.nscales || !c->d_xyb_ref || !c->have_ref || c->ref_w != w || c->ref_h != h)
             return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference XYB for that level");
         src = c->d_xyb_ref + xyb_off(p, scale);
+    } else if (what == SSIMU2_DEBUG_REF_BLUR) {
+        if (scale < 0 || scale >= p.nscales || !c->d_ref_blur || !c->have_ref || c->ref_w != w || c->ref_h != h)
+            return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference blur for that level");
+        src = c->d_ref_blur + xyb_off(p, scale);
     } else {
         return c->fail(SSIMU2_ERR_INVALID_ARG, "bad `what`");
     }

@@ -377,6 +377,19 @@ void or_blur_plane(const float* in, uint32_t w, uint32_t h, int mode, float* out
     free(tmp);
 }
 
+/* exported for tests: blur the product plane a*b the way the score does in `mode` */
+void or_blur_product(const float* a, const float* b, uint32_t w, uint32_t h, int mode, float* out) {
+    or_gauss rg;
+    or_gauss_create(1.5, &rg);
+    const size_t n = (size_t)w * h;
+    float* tmp = (float*)malloc(sizeof(float) * n);
+    float* prod = (float*)malloc(sizeof(float) * n);
+    if (mode == OR_BLUR_EXACT) blur_plane_exact(&rg, a, b, w, h, out);
+    else blur_plane_prod(&rg, mode, a, b, w, h, prod, tmp, out);
+    free(tmp);
+    free(prod);
+}
+
 /* ---- colour: 8-bit sRGB -> linear -> XYB ------------------------------------------ */
 
 void or_srgb_lut(float* lut256) {

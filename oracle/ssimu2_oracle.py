@@ -60,6 +60,8 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
         lib.or_compute_ssimu2.restype = ctypes.c_int
         lib.or_blur_plane.argtypes = [f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, f32p]
         lib.or_blur_plane.restype = None
+        lib.or_blur_product.argtypes = [f32p, f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, f32p]
+        lib.or_blur_product.restype = None
         lib.or_gauss_taps.argtypes = [f64p, f32p, f64p, f64p]
         lib.or_gauss_taps.restype = None
         lib.or_srgb_lut.argtypes = [f32p]
@@ -123,6 +125,16 @@ def blur_plane(plane: np.ndarray, blur: int = BLUR_IIR) -> np.ndarray:
     h, w = plane.shape
     out = np.empty_like(plane)
     _lib().or_blur_plane(_f32(plane), w, h, blur, _f32(out))
+    return out
+
+
+def blur_product(a: np.ndarray, b: np.ndarray, blur: int = BLUR_FIR) -> np.ndarray:
+    """blur(a * b) of two (h, w) float32 planes the way the score forms it in mode `blur`."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    h, w = a.shape
+    out = np.empty_like(a)
+    _lib().or_blur_product(_f32(a), _f32(b), w, h, blur, _f32(out))
     return out
 
 

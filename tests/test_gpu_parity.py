@@ -487,6 +487,31 @@ def test_intermediate_planes_are_bit_identical(iscorer, oracle, w, h):
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), s
 
 
+@pytest.mark.parametrize("w,h", [(333, 217), (121, 9), (640, 360), (1000, 700), (1921, 1083), (3840, 2160)])
+def test_blur_waves_output_is_bit_identical(iscorer, oracle, w, h):
+    """The blur itself, bit for bit: blur(ref * ref) of every XYB channel at every scale, as the
+    marching body's blur waves write it in emit mode (k_ref_blur: the same horizontal pass with
+    the products fused into the pair sums, the same register-window vertical pass, zero padding,
+    strips and segments as in k_march), equals the oracle's FIR planes exactly -- across strip
+    (120 columns) and segment boundaries and at the frame border.  And it is within 2 ulp-ish of
+    the fp64 evaluation of the same operator (the independent anchor, per pixel)."""
+    ref = synth.make_ref(w, h, 7 * w + h)
+    iscorer.set_reference(ref)
+    lin = np.ascontiguousarray(oracle.srgb_lut()[ref].transpose(2, 0, 1))
+    s = 0
+    while True:
+        xyb = oracle.linear_to_xyb(lin)
+        got = iscorer.debug_download(3, s, w, h)
+        for c in range(3):
+            exp = oracle.blur_product(xyb[c], xyb[c], oracle.BLUR_FIR)
+            assert np.array_equal(got[c].view(np.uint32), exp.view(np.uint32)), (s, c)
+            exact = oracle.blur_product(xyb[c], xyb[c], oracle.BLUR_EXACT)
+            assert np.max(np.abs(got[c] - exact) / np.maximum(np.abs(exact), 1e-6)) < 1e-6, (s, c)
+        s += 1
+        if s >= 6 or lin.shape[1] < 8 or lin.shape[2] < 8:  # the published loop: next scale iff this one is >= 8x8
+            break
+        lin = oracle.downsample2(lin)
+
 def test_every_rgb8_colour_converts_bit_identically(iscorer, scorer, oracle):
     """All 2^24 8-bit colours, once each (4096 x 4096): the device's sRGB table, opsin mix,
     cube root and positive-XYB offsets give the oracle's bits for EVERY input the scorer can be
