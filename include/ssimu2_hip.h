@@ -71,6 +71,19 @@ int ssimu2_prefetch(int device);
 int ssimu2_prefetch_join(int device);
 void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
 
+/* Which blur the scorer evaluates.  fssimu2's source is not available to this repository, so
+   which of the two it follows is not known:
+     SSIMU2_BLUR_FIR        (default) the 9-tap impulse response of the published sigma-1.5
+                            recursive Gaussian, zero padding, fused kernels -- what bench.py measures;
+     SSIMU2_BLUR_RECURSIVE  the published recursion itself (libjxl FastGaussian: three second-order
+                            sections, products rounded to fp32 first, horizontal then vertical),
+                            operation for operation; about 4x slower (a recursion has no strips).
+   The two differ by the recursion's own fp32 rounding noise: typically 0.02, at most ~0.6 points.
+   Applies to every later score of the ctx; a cached reference is dropped.  Frames of more than
+   2^28 pixels are refused in recursive mode (144 bytes of planes per pixel). */
+enum { SSIMU2_BLUR_FIR = 0, SSIMU2_BLUR_RECURSIVE = 1 };
+int ssimu2_ctx_set_blur(ssimu2_ctx* ctx, int mode);
+
 /* Human-readable description of the last error on this ctx ("" if none).  The pointer
    stays valid until the next call on the ctx.  ctx == NULL returns the last creation
    error of the calling thread. */

@@ -25,7 +25,10 @@ extern "C" {
    blur(ref*ref) planes of that reference (written by the marching body in emit mode: the blur
    waves' arithmetic, downloadable).  `out` receives 3 planes of w_s*h_s floats; returns
    SSIMU2_ERR_INVALID_ARG if that level does not exist. */
-enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2, SSIMU2_DEBUG_REF_BLUR = 3 };
+enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2, SSIMU2_DEBUG_REF_BLUR = 3,
+       /* SSIMU2_BLUR_RECURSIVE: the FIFTEEN planes (5 * channel + {x, y, xx, yy, xy}) after the
+          horizontal / after both passes, of the scale processed last (`out`: 15 planes) */
+       SSIMU2_DEBUG_RG_H = 4, SSIMU2_DEBUG_RG_V = 5 };
 int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
                           uint32_t* out_w, uint32_t* out_h);
 
@@ -64,6 +67,9 @@ int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double*
    ssimu2_set_reference also caches blur(ref*ref). */
 int ssimu2_instr_set_segment_rows(ssimu2_ctx* ctx, int rows_scale0, int rows_other_scales);
 int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
+/* recursive mode: process scales 0..scale only, so that scale's planes stay downloadable
+   (the score of such a run is meaningless); negative = all scales again */
+int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* ctx, int scale);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -28,8 +28,11 @@ TQ_MAX_PASS = 12
 
 # every symbol the public headers declare; tests/test_abi.py checks that liboavif_hip.so exports
 # exactly these (and that the Zig shim / INTEGRATION.md bind nothing else)
+BLUR_FIR, BLUR_RECURSIVE = 0, 1   # ssimu2_ctx_set_blur (include/ssimu2_hip.h)
+
 EXPORTED_SYMBOLS = (
-    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_last_error",
+    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_ctx_set_blur",
+    "ssimu2_last_error",
     "ssimu2_score_rgb8", "ssimu2_set_reference", "ssimu2_score_against_reference",
     "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
     "ssimu2_enqueue_against_reference_device", "ssimu2_score_rgb8_device",
@@ -69,7 +72,8 @@ class TQSpecStats(ctypes.Structure):
 # include/ssimu2_hip_internal.h: only liboavif_hip_instr.so has these
 INSTR_SYMBOLS = ("ssimu2_debug_download", "ssimu2_time_device", "ssimu2_time_stage",
                  "ssimu2_time_march_rotating", "ssimu2_measure_read_stream",
-                 "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur")
+                 "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur",
+                 "ssimu2_instr_rg_stop_after_scale")
 
 TQ_MAX_FANOUT = 16
 BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
@@ -125,6 +129,9 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
         L.ssimu2_prefetch_join.restype = ci
     L.ssimu2_ctx_destroy.argtypes = [vp]
     L.ssimu2_ctx_destroy.restype = None
+    if hasattr(L, "ssimu2_ctx_set_blur"):   # absent from round-1 builds (scripts/gpu_ab.py loads those too)
+        L.ssimu2_ctx_set_blur.argtypes = [vp, ci]
+        L.ssimu2_ctx_set_blur.restype = ci
     L.ssimu2_last_error.argtypes = [vp]
     L.ssimu2_last_error.restype = ctypes.c_char_p
     L.ssimu2_score_rgb8.argtypes = [vp, u8p, u8p, u32, u32, u32, f64p]
@@ -158,6 +165,7 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
                                            ctypes.POINTER(ctypes.c_float)],
             "ssimu2_instr_set_segment_rows": [vp, ci, ci],
             "ssimu2_instr_cache_reference_blur": [vp, ci],
+            "ssimu2_instr_rg_stop_after_scale": [vp, ci],
         }
         for name, argtypes in sigs.items():
             if hasattr(L, name):  # scripts/gpu_ab.py also binds older builds that lack some hooks

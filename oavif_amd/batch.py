@@ -354,7 +354,8 @@ def main(argv=None) -> int:
 
     def encode_fn(i, path):
         if not hasattr(tls, "scorer"):  # one context (HIP stream + scratch) per worker thread
-            tls.scorer = Ssimu2(local_rank)
+            from . import cli
+            tls.scorer = Ssimu2(local_rank, blur=cli.blur_from_env())
             all_scorers.append(tls.scorer)
         return encode_image(tls.scorer, path, out_dir / names[i], args.score_tgt,
                             args.tolerance, args.max_pass, args.speed)

@@ -33,6 +33,19 @@ class CliError(Exception):
         self.name = name
 
 
+def blur_from_env():
+    """OAVIF_SSIMU2_BLUR=recursive selects the published recursive Gaussian (ssimu2_ctx_set_blur,
+    include/ssimu2_hip.h) for this run; unset / "fir" = the default fused kernels.  Read by the
+    host side only: the C library itself reads no environment."""
+    v = os.environ.get("OAVIF_SSIMU2_BLUR", "").strip().lower()
+    if v in ("", "fir"):
+        return None
+    if v in ("recursive", "iir"):
+        from . import _lib
+        return _lib.BLUR_RECURSIVE
+    raise CliError(f"OAVIF_SSIMU2_BLUR={v!r}: expected 'fir' or 'recursive'")
+
+
 def eprint(s: str = "", end: str = "\n") -> None:
     sys.stderr.write(s + end)
 
@@ -343,7 +356,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         from . import tq
         if scorer is None:
             from . import Ssimu2
-            scorer = Ssimu2(int(os.environ.get("LOCAL_RANK", "0")))
+            scorer = Ssimu2(int(os.environ.get("LOCAL_RANK", "0")), blur=blur_from_env())
             own_scorer = True
         cache = {}
 
@@ -360,7 +373,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
             # Not a CLI flag: the option surface stays the reference's (parse_args.zig:76-122).
             from . import Ssimu2
             dev = int(os.environ.get("LOCAL_RANK", "0"))
-            ctxs = [scorer] + [Ssimu2(dev) for _ in range(min(fan, 16) - 1)]
+            ctxs = [scorer] + [Ssimu2(dev, blur=blur_from_env()) for _ in range(min(fan, 16) - 1)]
 
             def codec_keep(q: int):
                 data = _encode(src, o, q)

@@ -30,6 +30,7 @@
 
 #include "../../include/ssimu2_hip.h"
 #include "ssimu2_kernels.h"
+#include "ssimu2_recursive.h"
 
 using namespace ssimu2;
 
@@ -58,7 +59,7 @@ const double kWeightsHost[108] = {
 
 // FIR taps of the sigma = 1.5 recursive Gaussian (Charalampidis 2016 truncated cosines,
 // N = 5): w(d) = sum_k n2_k / sin(w_k) * sin(w_k (d + N)); see DESIGN.md "Blur".
-void gaussian_taps(double sigma, float taps[5]) {
+void gaussian_taps(double sigma, float taps[5], float n2_out[3], float d1_out[3]) {
     const double kPi = 3.141592653589793238;
     const double radius = round(3.2795 * sigma + 0.2546);
     const double pi_div_2r = kPi / (2.0 * radius);
@@ -90,6 +91,11 @@ void gaussian_taps(double sigma, float taps[5]) {
             wsum += n2 / sin(om[k]) * sin(om[k] * (t + radius));
         }
         taps[t] = (float)wsum;
+    }
+    // the recursion itself (SSIMU2_BLUR_RECURSIVE): input gain and feedback of each section
+    for (int k = 0; k < 3; ++k) {
+        n2_out[k] = (float)(-beta[k] * cos(om[k] * (radius + 1.0)));
+        d1_out[k] = (float)(-2.0 * cos(om[k]));
     }
 }
 
@@ -140,6 +146,11 @@ struct ssimu2_ctx {
     size_t cap_stage = 0;
     size_t cap_xyb = 0;
     double* d_partials = nullptr;
+    // SSIMU2_BLUR_RECURSIVE only (ssimu2_recursive.h): XYB of both frames + 15 + 15 blurred planes of one scale
+    int blur_mode = SSIMU2_BLUR_FIR;
+    float* d_rg = nullptr;
+    size_t cap_rg = 0;            // floats
+    double* d_rg_part = nullptr;  // [scale][18][RG_MAPS_BLOCKS]
     double* d_result = nullptr;   // 110 doubles
     double* h_result = nullptr;   // pinned mirror
 
@@ -153,6 +164,7 @@ struct ssimu2_ctx {
     int seg_rows_override = 0;
     int seg_rows_tail_override = 0;
     bool cache_ref_blur = true;
+    int rg_stop_after_scale = kNumScales;  // recursive mode: leave that scale's planes in d_rg
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
@@ -248,6 +260,11 @@ void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_ref_blur);
     c->d_ref_blur = nullptr;
     c->cap_blur = 0;
+    (void)hipFree(c->d_rg);
+    (void)hipFree(c->d_rg_part);
+    c->d_rg = nullptr;
+    c->d_rg_part = nullptr;
+    c->cap_rg = 0;
     c->d_ref_u8 = c->d_dist_u8 = nullptr;
     c->d_lin_ref = c->d_lin_dist = nullptr;
     c->d_partials = nullptr;
@@ -347,6 +364,65 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
     *total_blocks = blocks;
 }
 
+// The published-recursion mode (ssimu2_recursive.h): per scale XYB of both frames, horizontal and
+// vertical recursive passes of the 15 planes, maps; the linear pyramids are already enqueued.
+int enqueue_recursive(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, const uint8_t* d_dist) {
+    const size_t n0 = (size_t)p.w[0] * p.h[0];
+    const size_t need = 36 * n0;
+    if (need > c->cap_rg) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_rg);
+        c->d_rg = nullptr;
+        c->cap_rg = 0;
+        const hipError_t e = hipMalloc(&c->d_rg, need * sizeof(float));
+        if (e != hipSuccess) {
+            c->d_rg = nullptr;
+            return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur planes: 144 bytes per pixel)", e);
+        }
+        c->cap_rg = need;
+    }
+    if (!c->d_rg_part) {
+        const hipError_t e = hipMalloc(&c->d_rg_part, sizeof(double) * kNumScales * kStats * RG_MAPS_BLOCKS);
+        if (e != hipSuccess) {
+            c->d_rg_part = nullptr;
+            return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur partial sums)", e);
+        }
+    }
+    FinalizeArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.nscales = p.nscales;
+    for (int s = 0; s < p.nscales && s <= c->rg_stop_after_scale; ++s) {
+        const int w = p.w[s], h = p.h[s];
+        const size_t n = (size_t)w * h;
+        RgArgs a;
+        float* xa = c->d_rg;
+        float* xb = xa + 3 * n0;
+        a.xa = xa;
+        a.xb = xb;
+        a.hout = xb + 3 * n0;
+        a.vout = a.hout + 15 * n0;
+        a.w = w;
+        a.h = h;
+        const void* in_a = s == 0 ? (const void*)d_ref : (const void*)(c->d_lin_ref + p.lin_off[s]);
+        const void* in_b = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
+        const unsigned xyb_blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_a, s == 0, w, h, xa);
+        hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_b, s == 0, w, h, xb);
+        hipLaunchKernelGGL(k_rg_h, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_rg_v, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
+        double* part = c->d_rg_part + (size_t)s * kStats * RG_MAPS_BLOCKS;
+        hipLaunchKernelGGL(k_rg_maps, dim3(RG_MAPS_BLOCKS, 3), dim3(256), 0, c->stream, a, part);
+        fa.part[s] = part;
+        fa.nblocks[s] = RG_MAPS_BLOCKS;
+        fa.inv_pixels[s] = 1.0 / ((double)w * (double)h);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, 110 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    c->pending = true;
+    return SSIMU2_OK;
+}
+
 // Enqueue the whole score of (d_ref, d_dist) on the ctx stream.  `ref_pyramid_ready`:
 // the reference's linear pyramid in d_lin_ref is already valid for this frame size.
 int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, uint32_t w,
@@ -362,6 +438,11 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
             float* lin[2] = {c->d_lin_ref, c->d_lin_dist};
             launch_pyramid(c, p, 2, frames, lin);
         }
+    }
+    if (c->blur_mode == SSIMU2_BLUR_RECURSIVE) {
+        if ((uint64_t)w * h > (1ull << 28))
+            return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive blur mode: image larger than 2^28 pixels");
+        return enqueue_recursive(c, p, d_ref, d_dist);
     }
     MarchPlan mp;
     FinalizeArgs fa;
@@ -394,7 +475,17 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v4 (pair ring, b64 taps, dword pixel loads)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v5 (pair ring, b64 taps, dword pixel loads; optional recursive blur)"; }
+
+int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (mode != SSIMU2_BLUR_FIR && mode != SSIMU2_BLUR_RECURSIVE)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "unknown blur mode");
+    if (c->pending) return c->fail(SSIMU2_ERR_INVALID_ARG, "ssimu2_ctx_set_blur: a score is still enqueued");
+    c->blur_mode = mode;
+    c->have_ref = false;
+    return SSIMU2_OK;
+}
 
 const char* ssimu2_last_error(const ssimu2_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
@@ -497,7 +588,7 @@ static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
                 const double v = (double)i / 255.0;
                 k->lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
             }
-            gaussian_taps(1.5, k->taps);
+            gaussian_taps(1.5, k->taps, k->rg_n2, k->rg_d1);
             k->cbrt_bias = cbrt_repro_host(kOpsinBias);
             memcpy(k->weights, kWeightsHost, sizeof kWeightsHost);
             hipError_t ec = hipMemcpyToSymbol(HIP_SYMBOL(c_k), k, sizeof(DevConst));
@@ -581,6 +672,14 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
         const uint8_t* frames[1] = {c->d_ref_u8};
         float* lin[1] = {c->d_lin_ref};
         launch_pyramid(c, p, 1, frames, lin);
+    }
+    if (c->blur_mode == SSIMU2_BLUR_RECURSIVE) {  // that mode caches the pyramid only
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `ref` after return
+        c->have_ref = true;
+        c->ref_w = w;
+        c->ref_h = h;
+        return SSIMU2_OK;
     }
     // ... and its positive-XYB planes at every scale, so that the per-pass kernel skips the
     // LUT / opsin / cube-root work for the reference frame (same values, bit-identical scores)

@@ -56,6 +56,12 @@ int ssimu2_instr_set_segment_rows(ssimu2_ctx* c, int rows_scale0, int rows_other
     return SSIMU2_OK;
 }
 
+int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* c, int scale) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    c->rg_stop_after_scale = scale < 0 ? kNumScales : scale;
+    return SSIMU2_OK;
+}
+
 int ssimu2_instr_cache_reference_blur(ssimu2_ctx* c, int enabled) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
     c->cache_ref_blur = enabled != 0;
@@ -76,6 +82,18 @@ int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32
         if (scale < 0 || scale >= p.nscales || !c->d_xyb_ref || !c->have_ref || c->ref_w != w || c->ref_h != h)
             return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference XYB for that level");
         src = c->d_xyb_ref + xyb_off(p, scale);
+    } else if (what == SSIMU2_DEBUG_RG_H || what == SSIMU2_DEBUG_RG_V) {
+        // 15 planes of the scale the recursive mode processed last (ssimu2_instr_rg_stop_after_scale)
+        if (scale < 0 || scale >= p.nscales || !c->d_rg) return c->fail(SSIMU2_ERR_INVALID_ARG, "no recursive-blur planes");
+        const size_t n0 = (size_t)p.w[0] * p.h[0];
+        if (36 * n0 > c->cap_rg) return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive-blur planes are of another frame size");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const float* src15 = c->d_rg + 6 * n0 + (what == SSIMU2_DEBUG_RG_V ? 15 * n0 : 0);
+        HIP_TRY(c, hipMemcpy(out, src15, (size_t)15 * p.w[scale] * p.h[scale] * sizeof(float), hipMemcpyDeviceToHost));
+        if (out_w) *out_w = (uint32_t)p.w[scale];
+        if (out_h) *out_h = (uint32_t)p.h[scale];
+        return SSIMU2_OK;
     } else if (what == SSIMU2_DEBUG_REF_BLUR) {
         if (scale < 0 || scale >= p.nscales || !c->d_ref_blur || !c->have_ref || c->ref_w != w || c->ref_h != h)
             return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference blur for that level");

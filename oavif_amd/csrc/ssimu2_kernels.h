@@ -39,6 +39,8 @@ struct DevConst {
     float lut[256];     // 8-bit sRGB -> linear, fp32(rounded from fp64)
     float taps[5];      // FIR taps |d| = 0..4 of the sigma-1.5 recursive Gaussian
     float cbrt_bias;    // cbrt_repro(kOpsinBias)
+    float rg_n2[3];     // the recursion itself (ssimu2_recursive.h): input gains of the three sections
+    float rg_d1[3];     // ... and their feedback coefficients -2 cos(omega_k)
     double weights[108];
 };
 __constant__ DevConst c_k;

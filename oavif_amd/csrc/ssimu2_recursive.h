@@ -1,0 +1,247 @@
+// SSIMULACRA2 with the PUBLISHED blur: the recursive Gaussian of libjxl's ssimulacra2 (three
+// second-order sections driven by in[n-N-1] + in[n+N-1], N = 5 for sigma 1.5; Charalampidis 2016),
+// applied to the materialised product planes, horizontally then vertically -- the optional
+// SSIMU2_BLUR_RECURSIVE mode of a scorer context (include/ssimu2_hip.h).
+//
+// Why it exists: fssimu2's source is not available, the default kernels
+// evaluate the recursion's 9-tap impulse response instead (k_march), and the two differ by the
+// recursion's own rounding noise (up to 0.57 points).  This mode follows the
+// published operation order exactly -- the CPU checker's OR_BLUR_IIR planes are reproduced bit for
+// bit -- so a maintainer who can run fssimu2 can see which of the two it agrees with.
+//
+// A recursion cannot be cut into strips or segments: every output depends on the whole line
+// before it.  Parallelism is therefore lines x planes only (15 planes per scale: x, y, xx, yy, xy
+// of three channels), ~1 wave per SIMD at 4K, each lane a chain of 2,160-3,840 dependent steps:
+// this mode is latency-bound by construction (about 4x the time of the default kernels at 4K)
+// and is not what `bench.py` measures.
+//
+//   k_rg_h     lane = image row.  Tiles of 32 columns go through LDS (coalesced global loads and
+//              stores, transposed access by the recursion); the products are formed on load.
+//   k_rg_v     lane = image column: coalesced as it is; loads issued 8 rows ahead.
+//   k_rg_maps  SSIM and edge-difference maps from the 15 blurred planes + the two XYB frames,
+//              partial sums in the layout k_finalize reduces.
+#pragma once
+
+namespace ssimu2 {
+
+constexpr int RG_N = 5;                // radius of the sigma-1.5 recursion: round(3.2795 sigma + 0.2546)
+constexpr int RG_TILE = 32;            // columns per LDS tile of the horizontal pass
+constexpr int RG_RING = 2 * RG_TILE;   // ring of two tiles: the recursion looks 10 columns back
+constexpr int RG_MAPS_BLOCKS = 256;    // partial-sum blocks per scale and channel triple
+
+struct RgArgs {
+    const float* xa;  // positive-XYB planes of the reference  [3][h][w]
+    const float* xb;  // ... of the distorted frame
+    float* hout;      // horizontal pass of the 15 planes     [15][h][w], plane = 5 * channel + kind
+    float* vout;      // vertical pass of those
+    int w, h;
+};
+
+// kind: 0 = x, 1 = y, 2 = x*x, 3 = y*y, 4 = x*y (the product rounded to fp32 first, as published)
+__device__ __forceinline__ float rg_source(const float* a, const float* b, int kind, size_t i) {
+    if (kind == 0) return a[i];
+    if (kind == 1) return b[i];
+    if (kind == 2) {
+        const float v = a[i];
+        return v * v;
+    }
+    if (kind == 3) {
+        const float v = b[i];
+        return v * v;
+    }
+    return a[i] * b[i];
+}
+
+// state of the three sections of one line
+struct RgState {
+    float p1[3], p2[3];  // previous and second-previous output of each section
+};
+
+// one step of the recursion (FastGaussian1D, scalar form, no fused multiply-add):
+//   o_k = n2_k * (left + right) - prev2_k - d1_k * prev_k;   out = (o_1 + o_3) + o_5
+__device__ __forceinline__ float rg_step(RgState& s, float left, float right, const float (&n2)[3],
+                                         const float (&d1)[3]) {
+    const float sum = left + right;
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = sum * n2[k];
+        v = v - s.p2[k];
+        v = v - d1[k] * s.p1[k];
+        o[k] = v;
+        s.p2[k] = s.p1[k];
+        s.p1[k] = v;
+    }
+    return (o[0] + o[1]) + o[2];
+}
+
+// Horizontal pass.  One wave per (block of 64 rows, plane); grid = (ceil(h / 64), 15).
+__global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
+    __shared__ float s_in[64][RG_RING + 1];
+    __shared__ float s_out[64][RG_RING + 1];
+    const int lane = threadIdx.x;
+    const int plane = blockIdx.y, ch = plane / 5, kind = plane - 5 * ch;
+    const int w = a.w, h = a.h;
+    const int r0 = blockIdx.x * 64;
+    const size_t n = (size_t)w * h;
+    const float* xa = a.xa + ch * n;
+    const float* xb = a.xb + ch * n;
+    float* out = a.hout + plane * n;
+    const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
+    const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
+    RgState st;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
+    // tile access: lane -> (row lane / 32 + 2 j, column lane % 32): 128 contiguous bytes per row
+    const int tc = lane & (RG_TILE - 1), tr = lane >> 5;
+    const int ntiles = (w + 4 + RG_TILE - 1) / RG_TILE;  // m = n + 4 runs to w + 3
+    // Software pipeline: the 32 global loads of tile t + 1 are issued before the 32 recursion
+    // steps of tile t and land under them (a lone wave per SIMD hides nothing by itself).
+    float nxt[32];
+    // Branch-free (clamped address, value selected afterwards; plane kinds as a pointer pair and a
+    // uniform flag) so that all 32 loads of a tile are in flight together.
+    const float* srcp = (kind == 1 || kind == 3) ? xb : xa;
+    const float* srcq = kind == 2 ? xa : xb;
+    const bool prod = kind >= 2;
+#define RG_LOAD_TILE(T)                                                                  \
+    {                                                                                    \
+        const int col_ = (T) * RG_TILE + tc;                                             \
+        const int colc_ = min(col_, w - 1);                                              \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                 \
+            const int row_ = r0 + tr + 2 * j;                                            \
+            const size_t at_ = (size_t)min(row_, h - 1) * w + colc_;                     \
+            const float pv_ = srcp[at_];                                                 \
+            const float qv_ = srcq[at_];                                                 \
+            const float v_ = prod ? pv_ * qv_ : pv_;                                     \
+            /* x * 1 and x * 0 are exact for the finite, non-negative XYB values; a select */ \
+            /* here is turned into a branch around the load, one wait per load */       \
+            nxt[j] = v_ * ((col_ < w && row_ < h) ? 1.0f : 0.0f);                        \
+        }                                                                                \
+    }
+    RG_LOAD_TILE(0)
+    for (int t = 0; t <= ntiles; ++t) {
+        if (t < ntiles) {
+            // tile t into the ring; zero beyond the line's end (the published zero padding)
+            const int slot = (t * RG_TILE + tc) & (RG_RING - 1);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) s_in[tr + 2 * j][slot] = nxt[j];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) RG_LOAD_TILE(t + 1)
+        if (t < ntiles) {
+            // 32 steps of this lane's row: m = right-hand input column, output column m - 4
+#pragma unroll 8
+            for (int mm = 0; mm < RG_TILE; ++mm) {
+                const int m = t * RG_TILE + mm;
+                const float right = s_in[lane][m & (RG_RING - 1)];
+                const float left = m >= 2 * RG_N ? s_in[lane][(m - 2 * RG_N) & (RG_RING - 1)] : 0.f;
+                const float o = rg_step(st, left, right, n2, d1);
+                if (m >= RG_N - 1) s_out[lane][(m - (RG_N - 1)) & (RG_RING - 1)] = o;
+            }
+        }
+        __syncthreads();
+        // after tile t the outputs of columns < 32 t + 28 exist: flush output tile t - 1
+        if (t >= 1) {
+            const int col = (t - 1) * RG_TILE + tc;
+            if (col < w) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int row = r0 + tr + 2 * j;
+                    if (row < h) out[(size_t)row * w + col] = s_out[tr + 2 * j][col & (RG_RING - 1)];
+                }
+            }
+        }
+    }
+#undef RG_LOAD_TILE
+}
+
+// Vertical pass of the 15 horizontally blurred planes.  lane = column; grid = (ceil(w / 64), 15).
+__global__ __launch_bounds__(64) void k_rg_v(RgArgs a) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int w = a.w, h = a.h;
+    if (x >= w) return;
+    const size_t n = (size_t)w * h;
+    const float* in = a.hout + blockIdx.y * n + x;
+    float* out = a.vout + blockIdx.y * n + x;
+    const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
+    const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
+    RgState st;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
+    constexpr int U = 8;  // rows per batch; the next batch's 16 loads are in flight under this one's steps
+    float right[U], left[U], nright[U], nleft[U];
+#define RG_LOAD_ROWS(M0, R, L)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < U; ++j) {                                                  \
+        const int m_ = (M0) + j; /* uniform */                                                       \
+        R[j] = m_ < h ? in[(size_t)m_ * w] : 0.f;                                                    \
+        L[j] = (m_ >= 2 * RG_N && m_ - 2 * RG_N < h) ? in[(size_t)(m_ - 2 * RG_N) * w] : 0.f;        \
+    }
+    RG_LOAD_ROWS(0, nright, nleft)
+    for (int m0 = 0; m0 < h + RG_N - 1; m0 += U) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            right[j] = nright[j];
+            left[j] = nleft[j];
+        }
+        if (m0 + U < h + RG_N - 1) RG_LOAD_ROWS(m0 + U, nright, nleft)
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int m = m0 + j;
+            if (m < h + RG_N - 1) {
+                const float o = rg_step(st, left[j], right[j], n2, d1);
+                if (m >= RG_N - 1) out[(size_t)(m - (RG_N - 1)) * w] = o;
+            }
+        }
+    }
+#undef RG_LOAD_ROWS
+}
+
+// Maps + partial sums.  grid = (RG_MAPS_BLOCKS, 3 channels), 256 threads; part[stat][block].
+__global__ __launch_bounds__(256) void k_rg_maps(RgArgs a, double* __restrict__ part) {
+    __shared__ double s_part[4][6];
+    const int ch = blockIdx.y, blk = blockIdx.x;
+    const size_t n = (size_t)a.w * a.h;
+    const size_t chunk = (n + RG_MAPS_BLOCKS - 1) / RG_MAPS_BLOCKS;
+    const size_t lo = (size_t)blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const float* v = a.vout + (size_t)ch * 5 * n;
+    const float* xa = a.xa + ch * n;
+    const float* xb = a.xb + ch * n;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float mu1 = v[i], mu2 = v[n + i], s11 = v[2 * n + i], s22 = v[3 * n + i], s12 = v[4 * n + i];
+        const float r1 = xa[i], r2 = xb[i];
+        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+        const float dm = mu1 - mu2;
+        const float num_m = fmaf(-dm, dm, 1.0f);
+        const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+        const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+        float d = 1.0f - div_rn(num_m * num_s, denom_s);
+        d = fmaxf(d, 0.0f);
+        const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+        const float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
+        const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
+        const float d2 = d * d, a2 = art * art, t2 = det * det;
+        acc[0] += (double)d;
+        acc[1] += (double)(d2 * d2);
+        acc[2] += (double)art;
+        acc[3] += (double)(a2 * a2);
+        acc[4] += (double)det;
+        acc[5] += (double)(t2 * t2);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) s_part[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        const double s = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
+        // stat index as k_finalize reads it: 0..5 ssim (c*2 + n), 6..17 edge (c*4 + j)
+        const int stat = k < 2 ? ch * 2 + k : 6 + ch * 4 + (k - 2);
+        part[(size_t)stat * RG_MAPS_BLOCKS + blk] = s;
+    }
+}
+
+}  // namespace ssimu2

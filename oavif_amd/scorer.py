@@ -34,10 +34,12 @@ def _check_rgb8(a, name: str) -> np.ndarray:
 class Ssimu2:
     """One scorer context = one HIP stream + device scratch (not re-entrant)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None, instrumented: bool = False):
+    def __init__(self, device: int = 0, stream: int | None = None, instrumented: bool = False,
+                 blur: int | None = None):
         """`instrumented=True` binds liboavif_hip_instr.so (the hooks of
         include/ssimu2_hip_internal.h: stage timing, plane download, experiment knobs); the
-        default is the product library, which has none of them."""
+        default is the product library, which has none of them.  `blur`: _lib.BLUR_FIR /
+        _lib.BLUR_RECURSIVE (ssimu2_ctx_set_blur); None = FIR."""
         self.instrumented = bool(instrumented)
         self._L = _lib.instr_lib() if instrumented else _lib.lib()
         self._ctx = ctypes.c_void_p()
@@ -48,6 +50,8 @@ class Ssimu2:
             self._ctx = ctypes.c_void_p()
             raise Ssimu2Error(rc, msg or "ssimu2_ctx_create failed")
         self.device = device
+        if blur is not None and int(blur) != _lib.BLUR_FIR:
+            self.set_blur(blur)
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -197,13 +201,28 @@ class Ssimu2:
             self._raise(rc)
         return out.value
 
+    def set_blur(self, mode: int) -> None:
+        """ssimu2_ctx_set_blur: _lib.BLUR_FIR (default, the fused 9-tap kernels) or
+        _lib.BLUR_RECURSIVE (the published recursion, operation for operation; ~4x slower)."""
+        rc = self._L.ssimu2_ctx_set_blur(self._ctx, int(mode))
+        if rc != 0:
+            self._raise(rc)
+
+    def rg_stop_after_scale(self, scale: int) -> None:
+        """Instrumented build: the recursive mode processes scales 0..scale only, so that scale's
+        15 planes stay downloadable (debug_download what = 4 / 5); negative = all scales."""
+        self._need_instr()
+        rc = self._L.ssimu2_instr_rg_stop_after_scale(self._ctx, int(scale))
+        if rc != 0:
+            self._raise(rc)
+
     def debug_download(self, what: int, scale: int, w: int, h: int) -> np.ndarray:
-        """-> (3, h_s, w_s) float32 planes (see ssimu2_debug_download)."""
+        """-> (3, h_s, w_s) float32 planes; (15, h_s, w_s) for what = 4 / 5 (see ssimu2_debug_download)."""
         self._need_instr()
         sw, sh = w, h
         for _ in range(scale):
             sw, sh = (sw + 1) // 2, (sh + 1) // 2
-        out = np.empty((3, sh, sw), np.float32)
+        out = np.empty((15 if what in (4, 5) else 3, sh, sw), np.float32)
         ow, oh = ctypes.c_uint32(), ctypes.c_uint32()
         rc = self._L.ssimu2_debug_download(self._ctx, what, scale, w, h,
                                            out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),

@@ -32,6 +32,7 @@ extern fn ssimu2_ctx_create(device: c_int, hip_stream: ?*anyopaque, out_ctx: *?*
 extern fn ssimu2_prefetch(device: c_int) c_int;
 extern fn ssimu2_prefetch_join(device: c_int) c_int;
 extern fn ssimu2_ctx_destroy(ctx: ?*Ctx) void;
+extern fn ssimu2_ctx_set_blur(ctx: ?*Ctx, mode: c_int) c_int;
 extern fn ssimu2_last_error(ctx: ?*const Ctx) [*:0]const u8;
 extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: u32, h: u32, channels: u32, out_score: *f64) c_int;
 extern fn ssimu2_set_reference(ctx: ?*Ctx, ref: [*]const u8, w: u32, h: u32) c_int;
@@ -49,6 +50,15 @@ pub var device: c_int = 0;
 /// the reference buffer in place between calls; hosts that process several images per process
 /// should call invalidateReference() when an image's `e.rgb` is freed (INTEGRATION.md 2a).
 pub var cache_reference: bool = true;
+
+/// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur): `.fir`, the fused
+/// 9-tap kernels (default, what the benchmarks measure), or `.recursive`, the published recursive
+/// Gaussian operation for operation (about 15x slower at 4K, still ~2 ms per score).  The two
+/// differ by the recursion's own rounding noise (typically 0.02, at most ~0.6 points); which of
+/// them fssimu2 0.1.1 agrees with could not be checked where this shim was written.  Set before
+/// the first call.
+pub const Blur = enum(c_int) { fir = 0, recursive = 1 };
+pub var blur: Blur = .fir;
 
 var g_ctx: ?*Ctx = null;
 var g_ref_ptr: ?[*]const u8 = null;
@@ -74,6 +84,13 @@ fn context() Error!*Ctx {
     if (g_ctx) |c| return c;
     var c: ?*Ctx = null;
     try check(ssimu2_ctx_create(device, null, &c));
+    if (blur != .fir) {
+        const rc = ssimu2_ctx_set_blur(c, @intFromEnum(blur));
+        if (rc != 0) {
+            ssimu2_ctx_destroy(c);
+            try check(rc);
+        }
+    }
     g_ctx = c;
     return c.?;
 }

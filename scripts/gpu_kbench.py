@@ -55,4 +55,19 @@ for i in range(n):
 s.wait()
 dt = (time.perf_counter() - t0) / n
 print(f"cached-reference pass (rotating dist frames): {dt * 1e6:.1f} us/score  {w * h / 1e6 / dt:.0f} MP/s")
+# the published-recursion mode (ssimu2_ctx_set_blur): latency-bound by construction
+s.set_blur(oavif_amd._lib.BLUR_RECURSIVE)
+rscore = s.score_device(pr[0], pd[0], w, h)
+for i in range(4):
+    s.enqueue_device(pr[i % NP], pd[i % NP], w, h)
+s.wait()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 16
+for i in range(n):
+    s.enqueue_device(pr[i % NP], pd[i % NP], w, h)
+s.wait()
+dt = (time.perf_counter() - t0) / n
+print(f"recursive blur mode: score={rscore:.9f} (default mode {score:.9f})  {dt * 1e6:.1f} us/score  "
+      f"{w * h / 1e6 / dt:.0f} MP/s")
 s.close()

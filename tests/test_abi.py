@@ -77,6 +77,7 @@ def test_null_and_bad_arguments_return_codes(hip_lib):
     out = ctypes.c_double()
     assert hip_lib.ssimu2_score_against_reference(None, None, ctypes.byref(out)) == _lib.ERR_INVALID_ARG
     hip_lib.ssimu2_ctx_destroy(None)  # must be a no-op
+    assert hip_lib.ssimu2_ctx_set_blur(None, _lib.BLUR_RECURSIVE) == _lib.ERR_INVALID_ARG
     res = _lib.TQResult()
     assert hip_lib.oavif_tq_find_target_quality(None, _lib.PROBE_FN(lambda u, q, o: 0), None,
                                                 ctypes.byref(res)) == _lib.ERR_INVALID_ARG

@@ -1,0 +1,141 @@
+"""SSIMU2_BLUR_RECURSIVE (oavif_amd/csrc/ssimu2_recursive.h): the published recursive Gaussian on the
+GPU, against the oracle's OR_BLUR_IIR mode (the scalar form of libjxl's FastGaussian1D, restated in
+oracle/ssimu2_oracle.c).  -m gpu only.
+
+Tolerances: the 15 blurred planes of a scale BIT-IDENTICAL to the oracle's (the recursion has one
+evaluation order; products rounded to fp32 first, horizontal then vertical); scores to 1e-4 and
+the 108 averages to rtol 2e-5 (cube root / division / reduction order, as for the default mode).
+fssimu2 parity stays UNPINNED: which of the two blur modes it agrees with cannot be checked here.
+"""
+import numpy as np
+import pytest
+
+from oavif_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCORE = 1e-4
+RTOL_AVG = 2e-5
+
+
+@pytest.fixture()
+def rscorer(hip_lib):
+    from oavif_amd import Ssimu2
+    s = Ssimu2(0)
+    s.set_blur(_lib.BLUR_RECURSIVE)
+    yield s
+    s.close()
+
+
+@pytest.fixture()
+def irscorer(hip_lib):
+    from oavif_amd import Ssimu2
+    s = Ssimu2(0, instrumented=True)
+    s.set_blur(_lib.BLUR_RECURSIVE)
+    yield s
+    s.close()
+
+
+def _oracle_xyb_levels(oracle, img):
+    lin = np.ascontiguousarray(oracle.srgb_lut()[img].transpose(2, 0, 1))
+    levels = []
+    while True:
+        levels.append(oracle.linear_to_xyb(lin))
+        if len(levels) >= 6 or lin.shape[1] < 8 or lin.shape[2] < 8:
+            return levels
+        lin = oracle.downsample2(lin)
+
+
+@pytest.mark.parametrize("w,h", [(97, 61), (333, 217), (64, 64), (1000, 9), (9, 700), (640, 360)])
+def test_recursive_planes_are_bit_identical(irscorer, oracle, w, h):
+    """Every one of the 15 planes (x, y, xx, yy, xy of three channels) after both recursive
+    passes, at every scale, equals the oracle's OR_BLUR_IIR plane bit for bit."""
+    ref = synth.make_ref(w, h, 3 * w + h)
+    dist = synth.distort(ref, "blockq", 2, seed=4)
+    xa, xb = _oracle_xyb_levels(oracle, ref), _oracle_xyb_levels(oracle, dist)
+    for s in range(len(xa)):
+        irscorer.rg_stop_after_scale(s)
+        irscorer.compute_ssimu2(ref, dist)   # scales 0..s only: the score of this run means nothing
+        got = irscorer.debug_download(5, s, w, h)
+        for c in range(3):
+            a, b = xa[s][c], xb[s][c]
+            srcs = [a, b, a * a, b * b, a * b]   # products rounded to fp32 first, as published
+            for k in range(5):
+                exp = oracle.blur_plane(srcs[k], oracle.BLUR_IIR)
+                assert np.array_equal(got[5 * c + k].view(np.uint32), exp.view(np.uint32)), (s, c, k)
+    irscorer.rg_stop_after_scale(-1)
+
+
+@pytest.mark.parametrize("w,h,kind,strength", [(192, 144, "blockq", 2), (333, 217, "noise", 2), (8, 8, "noise", 3),
+                                               (127, 129, "blur", 2), (640, 360, "band", 3), (1920, 1080, "blockq", 1),
+                                               (5, 40, "noise", 2), (15, 15, "blockq", 3)])
+def test_recursive_score_matches_the_oracles_published_recursion(rscorer, oracle, w, h, kind, strength):
+    ref = synth.make_ref(w, h, w + 5 * h)
+    dist = synth.distort(ref, kind, strength, seed=2)
+    got = rscorer.compute_ssimu2(ref, dist)
+    avg_g, ns_g = rscorer.last_averages()
+    exp, avg_o, ns_o = oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR, return_averages=True)
+    assert ns_g == ns_o
+    assert np.allclose(avg_g, avg_o, rtol=RTOL_AVG, atol=1e-9), np.abs(avg_g - avg_o).max()
+    assert abs(got - exp) <= TOL_SCORE * max(1.0, abs(exp) / 100.0), (got, exp)
+    assert rscorer.compute_ssimu2(ref, ref) == 100.0
+
+
+def test_recursive_scores_of_the_golden_fixtures(rscorer, golden, anchors):
+    """The committed fixtures carry the oracle's published-recursion score (pairs_v1_anchors.json,
+    pinned on the CPU by tests/test_oracle.py): the GPU's recursive mode returns it."""
+    arrays, meta = golden
+    for p in meta["pairs"]:
+        ref, dist = arrays["ref"], arrays[p["name"]]
+        got = rscorer.compute_ssimu2(ref, dist)
+        assert abs(got - anchors[p["name"]]["score_iir"]) <= TOL_SCORE, (p["name"], got)
+
+
+def test_recursive_reference_path_and_mode_switch(rscorer, scorer, oracle):
+    """set_reference / score_against_reference in recursive mode return the pair score's bits;
+    switching the mode back returns the default mode's bits; a cached reference does not survive
+    a mode switch."""
+    from oavif_amd import Ssimu2Error
+    w, h = 500, 281
+    ref = synth.make_ref(w, h, 77)
+    dists = [synth.distort(ref, "blockq", k, seed=k) for k in (1, 2, 3)]
+    pair = [rscorer.compute_ssimu2(ref, d) for d in dists]
+    rscorer.set_reference(ref)
+    assert [rscorer.score_against_reference(d) for d in dists] == pair
+    fir = [scorer.compute_ssimu2(ref, d) for d in dists]
+    assert all(abs(a - b) < 0.7 for a, b in zip(pair, fir)) and pair != fir   # two blurs, two scores
+    rscorer.set_blur(_lib.BLUR_FIR)
+    with pytest.raises(Ssimu2Error):
+        rscorer.score_against_reference(dists[0])      # the cached reference was dropped
+    assert [rscorer.compute_ssimu2(ref, d) for d in dists] == fir
+    rscorer.set_blur(_lib.BLUR_RECURSIVE)
+    assert [rscorer.compute_ssimu2(ref, d) for d in dists] == pair
+    with pytest.raises(Ssimu2Error):
+        rscorer.set_blur(7)
+
+
+def test_recursive_4k_against_oracle(rscorer, oracle):
+    w, h = 3840, 2160
+    ref = synth.make_ref(w, h, 5)
+    dist = synth.distort(ref, "blockq", 2)
+    got = rscorer.compute_ssimu2(ref, dist)
+    exp = oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR)
+    assert abs(got - exp) <= TOL_SCORE, (got, exp)
+
+
+def test_env_selects_the_mode_for_cli_and_batch(hip_lib, monkeypatch, rscorer):
+    """OAVIF_SSIMU2_BLUR is read by the Python host side (cli.blur_from_env), never by the library."""
+    from oavif_amd import Ssimu2, cli
+    ref = synth.make_ref(200, 120, 9)
+    dist = synth.distort(ref, "noise", 2)
+    monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "recursive")
+    with Ssimu2(0, blur=cli.blur_from_env()) as s:
+        assert s.compute_ssimu2(ref, dist) == rscorer.compute_ssimu2(ref, dist)
+    with Ssimu2(0) as s:   # the library itself ignores the variable
+        fir = s.compute_ssimu2(ref, dist)
+    monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "fir")
+    with Ssimu2(0, blur=cli.blur_from_env()) as s:
+        assert s.compute_ssimu2(ref, dist) == fir
+    monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "gauss")
+    with pytest.raises(cli.CliError):
+        cli.blur_from_env()
