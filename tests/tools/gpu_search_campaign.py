@@ -1,7 +1,9 @@
 """Quantizer-match campaign on the GPU box: the same target-quality search (tq.zig:124-210) driven
 by the HIP scorer and by the CPU oracle over many synthetic images x targets, real AVIF probes
 (Pillow libavif/aom, speed 9).  Requires identical probe sequences and final quantizers; reports
-the largest score difference seen on any probe.  Usage: gpu_search_campaign.py [N_IMAGES]"""
+the largest score difference seen on any probe.
+Usage: gpu_search_campaign.py [N_IMAGES] [fir|recursive]   (recursive: ssimu2_ctx_set_blur's
+published-recursion mode against the oracle's OR_BLUR_IIR)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,12 +14,13 @@ from oracle import ssimu2_oracle as orc
 from oracle import tq_oracle
 
 n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+recursive = len(sys.argv) > 2 and sys.argv[2] == "recursive"
 orc.build()
 rng = np.random.default_rng(2026)
 sizes = [(384, 256), (320, 320), (500, 281), (257, 199), (640, 360)]
 targets = [55.0, 65.0, 75.0, 80.0, 85.0, 92.0]
 bad, worst, total_passes, t0 = [], 0.0, 0, time.time()
-with oavif_amd.Ssimu2(0) as s:
+with oavif_amd.Ssimu2(0, blur=oavif_amd._lib.BLUR_RECURSIVE if recursive else None) as s:
     for i in range(n_images):
         w, h = sizes[i % len(sizes)]
         ref = synth.make_ref(w, h, 7000 + i)
@@ -32,7 +35,7 @@ with oavif_amd.Ssimu2(0) as s:
         for tgt in targets:
             g = tq.search_hip(s, ref, codec, score_tgt=tgt)
             c = tq_oracle.find_target_quality(
-                lambda q: orc.compute_ssimu2(ref, codec(q)[0], orc.BLUR_FIR), score_tgt=tgt)
+                lambda q: orc.compute_ssimu2(ref, codec(q)[0], orc.BLUR_IIR if recursive else orc.BLUR_FIR), score_tgt=tgt)
             same = [q for q, _ in g.history] == [q for q, _ in c.history] and g.q == c.q and g.num_pass == c.num_pass
             d = max(abs(a[1] - b[1]) for a, b in zip(g.history, c.history))
             worst = max(worst, d)
@@ -41,7 +44,7 @@ with oavif_amd.Ssimu2(0) as s:
                 bad.append((i, w, h, tgt, g.history, c.history))
         if (i + 1) % 10 == 0:
             print(f"  {i + 1} images, {total_passes} passes, worst |dscore| {worst:.3e}, mismatches {len(bad)}", flush=True)
-print(f"{n_images} images x {len(targets)} targets = {n_images * len(targets)} searches, {total_passes} passes in "
+print(f"[{'recursive' if recursive else 'fir'} blur] {n_images} images x {len(targets)} targets = {n_images * len(targets)} searches, {total_passes} passes in "
       f"{time.time() - t0:.1f}s: probe sequences and final quantizers identical in "
       f"{n_images * len(targets) - len(bad)} of {n_images * len(targets)}; worst |dscore| on a probe = {worst:.3e}")
 for b in bad[:10]:
