@@ -11,8 +11,12 @@ from oracle import ssimu2_oracle as orc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+# third argument "recursive": the scorer in ssimu2_ctx_set_blur's published-recursion mode
+# against the oracle's OR_BLUR_IIR (default: the fused FIR kernels against OR_BLUR_FIR)
+recursive = len(sys.argv) > 3 and sys.argv[3] == "recursive"
+OR_MODE = orc.BLUR_IIR if recursive else orc.BLUR_FIR
 rng = np.random.default_rng(seed)
-s = oavif_amd.Ssimu2(0)
+s = oavif_amd.Ssimu2(0, blur=oavif_amd._lib.BLUR_RECURSIVE if recursive else None)
 worst_score, worst_avg, bad = 0.0, 0.0, []
 t0 = time.time()
 for i in range(n_cases):
@@ -47,7 +51,7 @@ for i in range(n_cases):
     dist = np.ascontiguousarray(dist)
     got = s.compute_ssimu2(ref, dist)
     avg, ns = s.last_averages()
-    exp, eavg, ens = orc.compute_ssimu2(ref, dist, orc.BLUR_FIR, return_averages=True)
+    exp, eavg, ens = orc.compute_ssimu2(ref, dist, OR_MODE, return_averages=True)
     ds = abs(got - exp)
     da = float(np.max(np.abs(avg - eavg) / np.maximum(np.abs(eavg), 1e-9))) if ns else 0.0
     worst_score, worst_avg = max(worst_score, ds), max(worst_avg, da)
@@ -69,7 +73,7 @@ for i in range(n_cases):
         print(f"  {i + 1} cases, worst |dscore| {worst_score:.3e}, violations {len(bad)}", flush=True)
     if not ok:
         bad.append((i, w, h, int(kind), int(dk), got, exp, ns, ens))
-print(f"{n_cases} cases in {time.time()-t0:.1f}s: worst |dscore| = {worst_score:.3e}, worst rel avg dev (atol-free) = {worst_avg:.3e}, violations = {len(bad)}")
+print(f"[{'recursive' if recursive else 'fir'} blur] {n_cases} cases in {time.time()-t0:.1f}s: worst |dscore| = {worst_score:.3e}, worst rel avg dev (atol-free) = {worst_avg:.3e}, violations = {len(bad)}")
 for b in bad[:20]:
     print("  BAD", b)
 sys.exit(1 if bad else 0)
