@@ -77,7 +77,7 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
                             recursive Gaussian, zero padding, fused kernels -- what bench.py measures;
      SSIMU2_BLUR_RECURSIVE  the published recursion itself (libjxl FastGaussian: three second-order
                             sections, products rounded to fp32 first, horizontal then vertical),
-                            operation for operation; about 4x slower (a recursion has no strips).
+                            operation for operation; about 11x slower at 4K (a recursion has no strips).
    The two differ by the recursion's own fp32 rounding noise: typically 0.02, at most ~0.6 points.
    Applies to every later score of the ctx; a cached reference is dropped.  Frames of more than
    2^28 pixels are refused in recursive mode (144 bytes of planes per pixel). */

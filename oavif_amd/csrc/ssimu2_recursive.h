@@ -12,12 +12,12 @@
 // A recursion cannot be cut into strips or segments: every output depends on the whole line
 // before it.  Parallelism is therefore lines x planes only (15 planes per scale: x, y, xx, yy, xy
 // of three channels), ~1 wave per SIMD at 4K, each lane a chain of 2,160-3,840 dependent steps:
-// this mode is latency-bound by construction (about 4x the time of the default kernels at 4K)
+// this mode is latency-bound by construction (about 11x the time of the default kernels at 4K)
 // and is not what `bench.py` measures.
 //
 //   k_rg_h     lane = image row.  Tiles of 32 columns go through LDS (coalesced global loads and
 //              stores, transposed access by the recursion); the products are formed on load.
-//   k_rg_v     lane = image column: coalesced as it is; loads issued 8 rows ahead.
+//   k_rg_v     lane = image column: coalesced as it is; loads issued a batch of 10 rows ahead.
 //   k_rg_maps  SSIM and edge-difference maps from the 15 blurred planes + the two XYB frames,
 //              partial sums in the layout k_finalize reduces.
 #pragma once
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
     // Software pipeline: the 32 global loads of tile t + 1 are issued before the 32 recursion
     // steps of tile t and land under them (a lone wave per SIMD hides nothing by itself).
     float nxt[32];
+    float prev[2 * RG_N];
+#pragma unroll
+    for (int k = 0; k < 2 * RG_N; ++k) prev[k] = 0.f;
     // Branch-free (clamped address, value selected afterwards; plane kinds as a pointer pair and a
     // uniform flag) so that all 32 loads of a tile are in flight together.
     const float* srcp = (kind == 1 || kind == 3) ? xb : xa;
@@ -129,15 +132,22 @@ __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
         __syncthreads();
         if (t + 1 < ntiles) RG_LOAD_TILE(t + 1)
         if (t < ntiles) {
-            // 32 steps of this lane's row: m = right-hand input column, output column m - 4
-#pragma unroll 8
+            // 32 steps of this lane's row: m = right-hand input column, output column m - 4.  The
+            // tile's 32 inputs are fetched from LDS in one batch; the left-hand input in[m - 10] is
+            // the right-hand one of ten steps ago and stays in registers (prev = the last ten of
+            // the previous tile; zeros before the line starts, the published padding).
+            float r[RG_TILE];
+#pragma unroll
+            for (int mm = 0; mm < RG_TILE; ++mm) r[mm] = s_in[lane][(t * RG_TILE + mm) & (RG_RING - 1)];
+#pragma unroll
             for (int mm = 0; mm < RG_TILE; ++mm) {
-                const int m = t * RG_TILE + mm;
-                const float right = s_in[lane][m & (RG_RING - 1)];
-                const float left = m >= 2 * RG_N ? s_in[lane][(m - 2 * RG_N) & (RG_RING - 1)] : 0.f;
-                const float o = rg_step(st, left, right, n2, d1);
-                if (m >= RG_N - 1) s_out[lane][(m - (RG_N - 1)) & (RG_RING - 1)] = o;
+                const float left = mm >= 2 * RG_N ? r[mm - 2 * RG_N] : prev[mm];
+                const float o = rg_step(st, left, r[mm], n2, d1);
+                if (t > 0 || mm >= RG_N - 1)  // uniform: the first four steps produce no output
+                    s_out[lane][(t * RG_TILE + mm - (RG_N - 1)) & (RG_RING - 1)] = o;
             }
+#pragma unroll
+            for (int k = 0; k < 2 * RG_N; ++k) prev[k] = r[RG_TILE - 2 * RG_N + k];
         }
         __syncthreads();
         // after tile t the outputs of columns < 32 t + 28 exist: flush output tile t - 1
@@ -168,22 +178,26 @@ __global__ __launch_bounds__(64) void k_rg_v(RgArgs a) {
     RgState st;
 #pragma unroll
     for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
-    constexpr int U = 8;  // rows per batch; the next batch's 16 loads are in flight under this one's steps
-    float right[U], left[U], nright[U], nleft[U];
-#define RG_LOAD_ROWS(M0, R, L)                                                                       \
-    _Pragma("unroll") for (int j = 0; j < U; ++j) {                                                  \
-        const int m_ = (M0) + j; /* uniform */                                                       \
-        R[j] = m_ < h ? in[(size_t)m_ * w] : 0.f;                                                    \
-        L[j] = (m_ >= 2 * RG_N && m_ - 2 * RG_N < h) ? in[(size_t)(m_ - 2 * RG_N) * w] : 0.f;        \
+    // Ten rows per batch: the left-hand input in[m - 10] of a step is the right-hand one of the
+    // same slot of the previous batch, so every row is loaded once; the next batch's loads are in
+    // flight under this one's steps.
+    constexpr int U = 2 * RG_N;
+    float right[U], left[U], nright[U];
+#define RG_LOAD_ROWS(M0, R)                                          \
+    _Pragma("unroll") for (int j = 0; j < U; ++j) {                  \
+        const int m_ = (M0) + j; /* uniform */                       \
+        R[j] = m_ < h ? in[(size_t)m_ * w] : 0.f;                    \
     }
-    RG_LOAD_ROWS(0, nright, nleft)
+#pragma unroll
+    for (int j = 0; j < U; ++j) right[j] = 0.f;  // rows -10 .. -1: the published zero padding
+    RG_LOAD_ROWS(0, nright)
     for (int m0 = 0; m0 < h + RG_N - 1; m0 += U) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
+            left[j] = right[j];
             right[j] = nright[j];
-            left[j] = nleft[j];
         }
-        if (m0 + U < h + RG_N - 1) RG_LOAD_ROWS(m0 + U, nright, nleft)
+        if (m0 + U < h + RG_N - 1) RG_LOAD_ROWS(m0 + U, nright)
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int m = m0 + j;
