@@ -5,7 +5,7 @@
 //
 // Why it exists: fssimu2's source is not available, the default kernels
 // evaluate the recursion's 9-tap impulse response instead (k_march), and the two differ by the
-// recursion's own rounding noise (up to 0.57 points).  This mode follows the
+// recursion's own rounding noise (median 0.5, up to 2.4 points at 4K).  This mode follows the
 // published operation order exactly -- the CPU checker's OR_BLUR_IIR planes are reproduced bit for
 // bit -- so a maintainer who can run fssimu2 can see which of the two it agrees with.
 //
