@@ -83,7 +83,11 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
    accumulated in fp64 the FIR form is within 0.0005 at 4K, the recursion about 1 point off.
    Applies to every later score of the ctx; a cached reference is dropped.  Frames of more than
    2^28 pixels are refused in recursive mode (144 bytes of planes per pixel). */
-enum { SSIMU2_BLUR_FIR = 0, SSIMU2_BLUR_RECURSIVE = 1 };
+enum { SSIMU2_BLUR_FIR = 0, SSIMU2_BLUR_RECURSIVE = 1,
+       /* the same recursion with its last multiply-subtract fused, fma(-d1, prev, .), the way a
+          compiler targeting an FMA unit contracts the published scalar code; the two orders are
+          0.6 points apart on a 4K probe */
+       SSIMU2_BLUR_RECURSIVE_FMA = 2 };
 int ssimu2_ctx_set_blur(ssimu2_ctx* ctx, int mode);
 
 /* Human-readable description of the last error on this ctx ("" if none).  The pointer

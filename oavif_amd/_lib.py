@@ -28,7 +28,7 @@ TQ_MAX_PASS = 12
 
 # every symbol the public headers declare; tests/test_abi.py checks that liboavif_hip.so exports
 # exactly these (and that the Zig shim / INTEGRATION.md bind nothing else)
-BLUR_FIR, BLUR_RECURSIVE = 0, 1   # ssimu2_ctx_set_blur (include/ssimu2_hip.h)
+BLUR_FIR, BLUR_RECURSIVE, BLUR_RECURSIVE_FMA = 0, 1, 2   # ssimu2_ctx_set_blur (include/ssimu2_hip.h)
 
 EXPORTED_SYMBOLS = (
     "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_ctx_set_blur",

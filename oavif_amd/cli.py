@@ -40,10 +40,12 @@ def blur_from_env():
     v = os.environ.get("OAVIF_SSIMU2_BLUR", "").strip().lower()
     if v in ("", "fir"):
         return None
+    from . import _lib
     if v in ("recursive", "iir"):
-        from . import _lib
         return _lib.BLUR_RECURSIVE
-    raise CliError(f"OAVIF_SSIMU2_BLUR={v!r}: expected 'fir' or 'recursive'")
+    if v in ("recursive_fma", "recursive-fma", "iir_fma"):
+        return _lib.BLUR_RECURSIVE_FMA
+    raise CliError(f"OAVIF_SSIMU2_BLUR={v!r}: expected 'fir', 'recursive' or 'recursive_fma'")
 
 
 def eprint(s: str = "", end: str = "\n") -> None:

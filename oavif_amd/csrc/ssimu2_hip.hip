@@ -408,8 +408,13 @@ int enqueue_recursive(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, con
         const unsigned xyb_blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_a, s == 0, w, h, xa);
         hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_b, s == 0, w, h, xb);
-        hipLaunchKernelGGL(k_rg_h, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
-        hipLaunchKernelGGL(k_rg_v, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
+        if (c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA) {
+            hipLaunchKernelGGL(k_rg_h<true>, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
+            hipLaunchKernelGGL(k_rg_v<true>, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
+        } else {
+            hipLaunchKernelGGL(k_rg_h<false>, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
+            hipLaunchKernelGGL(k_rg_v<false>, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
+        }
         double* part = c->d_rg_part + (size_t)s * kStats * RG_MAPS_BLOCKS;
         hipLaunchKernelGGL(k_rg_maps, dim3(RG_MAPS_BLOCKS, 3), dim3(256), 0, c->stream, a, part);
         fa.part[s] = part;
@@ -439,7 +444,7 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
             launch_pyramid(c, p, 2, frames, lin);
         }
     }
-    if (c->blur_mode == SSIMU2_BLUR_RECURSIVE) {
+    if (c->blur_mode != SSIMU2_BLUR_FIR) {
         if ((uint64_t)w * h > (1ull << 28))
             return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive blur mode: image larger than 2^28 pixels");
         return enqueue_recursive(c, p, d_ref, d_dist);
@@ -479,7 +484,7 @@ const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v5 (pair ring
 
 int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
-    if (mode != SSIMU2_BLUR_FIR && mode != SSIMU2_BLUR_RECURSIVE)
+    if (mode != SSIMU2_BLUR_FIR && mode != SSIMU2_BLUR_RECURSIVE && mode != SSIMU2_BLUR_RECURSIVE_FMA)
         return c->fail(SSIMU2_ERR_INVALID_ARG, "unknown blur mode");
     if (c->pending) return c->fail(SSIMU2_ERR_INVALID_ARG, "ssimu2_ctx_set_blur: a score is still enqueued");
     c->blur_mode = mode;
@@ -673,7 +678,7 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
         float* lin[1] = {c->d_lin_ref};
         launch_pyramid(c, p, 1, frames, lin);
     }
-    if (c->blur_mode == SSIMU2_BLUR_RECURSIVE) {  // that mode caches the pyramid only
+    if (c->blur_mode != SSIMU2_BLUR_FIR) {  // the recursive modes cache the pyramid only
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `ref` after return
         c->have_ref = true;

@@ -57,8 +57,12 @@ struct RgState {
     float p1[3], p2[3];  // previous and second-previous output of each section
 };
 
-// one step of the recursion (FastGaussian1D, scalar form, no fused multiply-add):
+// one step of the recursion (FastGaussian1D, scalar form):
 //   o_k = n2_k * (left + right) - prev2_k - d1_k * prev_k;   out = (o_1 + o_3) + o_5
+// FMA = false: every operation rounded by itself (the published scalar order);
+// FMA = true:  the last multiply-subtract fused, fma(-d1_k, prev_k, .), as a compiler targeting
+//              an FMA unit contracts it (SSIMU2_BLUR_RECURSIVE_FMA; the checker's OR_BLUR_IIR_FMA)
+template <bool FMA>
 __device__ __forceinline__ float rg_step(RgState& s, float left, float right, const float (&n2)[3],
                                          const float (&d1)[3]) {
     const float sum = left + right;
@@ -67,7 +71,8 @@ __device__ __forceinline__ float rg_step(RgState& s, float left, float right, co
     for (int k = 0; k < 3; ++k) {
         float v = sum * n2[k];
         v = v - s.p2[k];
-        v = v - d1[k] * s.p1[k];
+        if (FMA) v = fmaf(-d1[k], s.p1[k], v);
+        else v = v - d1[k] * s.p1[k];
         o[k] = v;
         s.p2[k] = s.p1[k];
         s.p1[k] = v;
@@ -76,6 +81,7 @@ __device__ __forceinline__ float rg_step(RgState& s, float left, float right, co
 }
 
 // Horizontal pass.  One wave per (block of 64 rows, plane); grid = (ceil(h / 64), 15).
+template <bool FMA>
 __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
     __shared__ float s_in[64][RG_RING + 1];
     __shared__ float s_out[64][RG_RING + 1];
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
 #pragma unroll
             for (int mm = 0; mm < RG_TILE; ++mm) {
                 const float left = mm >= 2 * RG_N ? r[mm - 2 * RG_N] : prev[mm];
-                const float o = rg_step(st, left, r[mm], n2, d1);
+                const float o = rg_step<FMA>(st, left, r[mm], n2, d1);
                 if (t > 0 || mm >= RG_N - 1)  // uniform: the first four steps produce no output
                     s_out[lane][(t * RG_TILE + mm - (RG_N - 1)) & (RG_RING - 1)] = o;
             }
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
 }
 
 // Vertical pass of the 15 horizontally blurred planes.  lane = column; grid = (ceil(w / 64), 15).
+template <bool FMA>
 __global__ __launch_bounds__(64) void k_rg_v(RgArgs a) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int w = a.w, h = a.h;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64) void k_rg_v(RgArgs a) {
         for (int j = 0; j < U; ++j) {
             const int m = m0 + j;
             if (m < h + RG_N - 1) {
-                const float o = rg_step(st, left[j], right[j], n2, d1);
+                const float o = rg_step<FMA>(st, left[j], right[j], n2, d1);
                 if (m >= RG_N - 1) out[(size_t)(m - (RG_N - 1)) * w] = o;
             }
         }

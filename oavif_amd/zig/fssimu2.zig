@@ -57,7 +57,7 @@ pub var cache_reference: bool = true;
 /// differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5 at 4K); which of
 /// them fssimu2 0.1.1 agrees with could not be checked where this shim was written.  Set before
 /// the first call.
-pub const Blur = enum(c_int) { fir = 0, recursive = 1 };
+pub const Blur = enum(c_int) { fir = 0, recursive = 1, recursive_fma = 2 };
 pub var blur: Blur = .fir;
 
 var g_ctx: ?*Ctx = null;

@@ -139,3 +139,33 @@ def test_env_selects_the_mode_for_cli_and_batch(hip_lib, monkeypatch, rscorer):
     monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "gauss")
     with pytest.raises(cli.CliError):
         cli.blur_from_env()
+
+
+@pytest.mark.parametrize("w,h", [(333, 217), (97, 61), (1000, 9)])
+def test_fused_recursion_order_planes_and_scores(hip_lib, oracle, w, h):
+    """SSIMU2_BLUR_RECURSIVE_FMA: the recursion with its last multiply-subtract fused (what an FMA
+    target makes of the published scalar code) = the oracle's OR_BLUR_IIR_FMA, planes bit for bit
+    and scores to 1e-4; and it is NOT the unfused order (the two are different functions)."""
+    from oavif_amd import Ssimu2
+    ref = synth.make_ref(w, h, 3 * w + h)
+    dist = synth.distort(ref, "blockq", 2, seed=4)
+    xa, xb = _oracle_xyb_levels(oracle, ref), _oracle_xyb_levels(oracle, dist)
+    with Ssimu2(0, instrumented=True, blur=_lib.BLUR_RECURSIVE_FMA) as s:
+        for sc in range(len(xa)):
+            s.rg_stop_after_scale(sc)
+            s.compute_ssimu2(ref, dist)
+            got = s.debug_download(5, sc, w, h)
+            for c in range(3):
+                a, b = xa[sc][c], xb[sc][c]
+                srcs = [a, b, a * a, b * b, a * b]
+                for k in range(5):
+                    exp = oracle.blur_plane(srcs[k], oracle.BLUR_IIR_FMA)
+                    assert np.array_equal(got[5 * c + k].view(np.uint32), exp.view(np.uint32)), (sc, c, k)
+        s.rg_stop_after_scale(-1)
+        fused = s.compute_ssimu2(ref, dist)
+        assert abs(fused - oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR_FMA)) <= TOL_SCORE
+        s.set_blur(_lib.BLUR_RECURSIVE)
+        unfused = s.compute_ssimu2(ref, dist)
+        assert abs(unfused - oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR)) <= TOL_SCORE
+        if min(w, h) >= 16:
+            assert fused != unfused
