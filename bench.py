@@ -405,6 +405,28 @@ def main() -> int:
                                    "note": "reference pyramid, XYB and blur(ref^2) planes cached by ssimu2_set_reference; "
                                            "one stream; separate from `value`"}
 
+        # ---- the optional published-recursion blur modes (ssimu2_ctx_set_blur): latency-bound
+        # by construction, reported beside, never `value` ---------------------------------------
+        from oavif_amd import _lib as _abi
+        with oavif_amd.Ssimu2(local_rank, blur=_abi.BLUR_RECURSIVE) as rsc:
+            r_score = rsc.score_device(p_ref, p_dst, w, h)
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            n_r = 12
+            for _ in range(n_r):
+                rsc.enqueue_device(p_ref, p_dst, w, h)
+            rsc.wait()
+            torch.cuda.synchronize()
+            r_ms = (time.perf_counter() - tt) / n_r * 1e3
+            rsc.set_blur(_abi.BLUR_RECURSIVE_FMA)
+            rf_score = rsc.score_device(p_ref, p_dst, w, h)
+        out["recursive_blur_mode"] = {
+            "ms_per_score": round(r_ms, 4), "MP_per_s": round(mp / r_ms * 1e3, 1),
+            "score_recursive": round(r_score, 6), "score_recursive_fma": round(rf_score, 6),
+            "score_default_fir": round(scores[0], 6),
+            "note": "SSIMU2_BLUR_RECURSIVE: the published recursive Gaussian operation for operation (planes "
+                    "bit-identical to the oracle's OR_BLUR_IIR); a recursion has no strips, one wave per SIMD"}
+
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
         scorer.set_reference(ref)
         scorer.score_against_reference(dst)
