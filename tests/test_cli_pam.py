@@ -174,3 +174,19 @@ def test_early_error_exit_after_prefetch_does_not_hang(tmp_path):
                        cwd=root, capture_output=True, text=True, timeout=120)
     assert p.returncode == 1
     assert "error: FileNotFound" in p.stderr
+
+
+def test_blur_mode_selector_from_environment(monkeypatch):
+    """OAVIF_SSIMU2_BLUR (host side only; the C library reads no environment): fir / recursive /
+    recursive_fma map to ssimu2_ctx_set_blur's modes, anything else is refused."""
+    from oavif_amd import _lib, cli
+    monkeypatch.delenv("OAVIF_SSIMU2_BLUR", raising=False)
+    assert cli.blur_from_env() is None
+    for text, mode in (("fir", None), ("recursive", _lib.BLUR_RECURSIVE), ("IIR", _lib.BLUR_RECURSIVE),
+                       ("recursive_fma", _lib.BLUR_RECURSIVE_FMA), (" recursive-fma ", _lib.BLUR_RECURSIVE_FMA)):
+        monkeypatch.setenv("OAVIF_SSIMU2_BLUR", text)
+        assert cli.blur_from_env() == mode
+    monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "gaussian")
+    with pytest.raises(cli.CliError):
+        cli.blur_from_env()
+    assert (_lib.BLUR_FIR, _lib.BLUR_RECURSIVE, _lib.BLUR_RECURSIVE_FMA) == (0, 1, 2)   # include/ssimu2_hip.h
