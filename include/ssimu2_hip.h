@@ -77,7 +77,7 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
                             recursive Gaussian, zero padding, fused kernels -- what bench.py measures;
      SSIMU2_BLUR_RECURSIVE  the published recursion itself (libjxl FastGaussian: three second-order
                             sections, products rounded to fp32 first, horizontal then vertical),
-                            operation for operation; about 11x slower at 4K (a recursion has no strips).
+                            operation for operation; about 9x slower at 4K (a recursion has no strips).
    The two differ by the recursion's own fp32 rounding noise, which grows with the line length:
    median 0.02 points on 384x256 frames, 0.13 at 1080p, 0.47 (max 2.4) at 4K; against the operator
    accumulated in fp64 the FIR form is within 0.0005 at 4K, the recursion about 1 point off.

@@ -12,11 +12,11 @@
 // A recursion cannot be cut into strips or segments: every output depends on the whole line
 // before it.  Parallelism is therefore lines x planes only (15 planes per scale: x, y, xx, yy, xy
 // of three channels), ~1 wave per SIMD at 4K, each lane a chain of 2,160-3,840 dependent steps:
-// this mode is latency-bound by construction (about 11x the time of the default kernels at 4K)
+// this mode is latency-bound by construction (about 9x the time of the default kernels at 4K)
 // and is not what `bench.py` measures.
 //
-//   k_rg_h     lane = image row.  Tiles of 32 columns go through LDS (coalesced global loads and
-//              stores, transposed access by the recursion); the products are formed on load.
+//   k_rg_h     lane = image row, streaming its own row 32 columns at a time as 16-byte loads and
+//              stores (no transposition, no LDS); the products are formed on load.
 //   k_rg_v     lane = image column: coalesced as it is; loads issued a batch of 10 rows ahead.
 //   k_rg_maps  SSIM and edge-difference maps from the 15 blurred planes + the two XYB frames,
 //              partial sums in the layout k_finalize reduces.
@@ -25,8 +25,7 @@
 namespace ssimu2 {
 
 constexpr int RG_N = 5;                // radius of the sigma-1.5 recursion: round(3.2795 sigma + 0.2546)
-constexpr int RG_TILE = 32;            // columns per LDS tile of the horizontal pass
-constexpr int RG_RING = 2 * RG_TILE;   // ring of two tiles: the recursion looks 10 columns back
+constexpr int RG_TILE = 32;            // columns per register tile of the horizontal pass
 constexpr int RG_MAPS_BLOCKS = 256;    // partial-sum blocks per scale and channel triple
 
 struct RgArgs {
@@ -81,89 +80,94 @@ __device__ __forceinline__ float rg_step(RgState& s, float left, float right, co
 }
 
 // Horizontal pass.  One wave per (block of 64 rows, plane); grid = (ceil(h / 64), 15).
+// lane = image row, and the lane streams ITS OWN row: 32 columns per tile as eight 16-byte loads
+// (a lane's eight loads share one 128-byte line, the L1 serves the repeats) into registers, 32
+// recursion steps, eight 16-byte stores -- no transposition, no LDS, no barrier, one pointer per
+// lane.  The loads of tile t + 1 are issued before the steps of tile t (a lone wave per SIMD hides
+// nothing by itself).  The last, partial tile of a row goes element by element.
+typedef float rg_f4 __attribute__((ext_vector_type(4)));
+
 template <bool FMA>
 __global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
-    __shared__ float s_in[64][RG_RING + 1];
-    __shared__ float s_out[64][RG_RING + 1];
     const int lane = threadIdx.x;
     const int plane = blockIdx.y, ch = plane / 5, kind = plane - 5 * ch;
     const int w = a.w, h = a.h;
-    const int r0 = blockIdx.x * 64;
+    const int row = blockIdx.x * 64 + lane;
+    const bool live = row < h;
     const size_t n = (size_t)w * h;
+    const size_t base = (size_t)min(row, h - 1) * w;  // idle lanes shadow the last row, never store
     const float* xa = a.xa + ch * n;
     const float* xb = a.xb + ch * n;
-    float* out = a.hout + plane * n;
+    // plane kinds as a pointer pair and a uniform flag: x, y, x*x, y*y, x*y
+    const float* srcp = ((kind == 1 || kind == 3) ? xb : xa) + base;
+    const float* srcq = (kind == 2 ? xa : xb) + base;
+    const bool prod = kind >= 2;
+    float* out = a.hout + plane * n + base;
     const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
     const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
     RgState st;
 #pragma unroll
     for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
-    // tile access: lane -> (row lane / 32 + 2 j, column lane % 32): 128 contiguous bytes per row
-    const int tc = lane & (RG_TILE - 1), tr = lane >> 5;
-    const int ntiles = (w + 4 + RG_TILE - 1) / RG_TILE;  // m = n + 4 runs to w + 3
-    // Software pipeline: the 32 global loads of tile t + 1 are issued before the 32 recursion
-    // steps of tile t and land under them (a lone wave per SIMD hides nothing by itself).
-    float nxt[32];
-    float prev[2 * RG_N];
+    float prev[2 * RG_N];  // the last ten inputs of the previous tile (zeros: the published padding)
 #pragma unroll
     for (int k = 0; k < 2 * RG_N; ++k) prev[k] = 0.f;
-    // Branch-free (clamped address, value selected afterwards; plane kinds as a pointer pair and a
-    // uniform flag) so that all 32 loads of a tile are in flight together.
-    const float* srcp = (kind == 1 || kind == 3) ? xb : xa;
-    const float* srcq = kind == 2 ? xa : xb;
-    const bool prod = kind >= 2;
-#define RG_LOAD_TILE(T)                                                                  \
-    {                                                                                    \
-        const int col_ = (T) * RG_TILE + tc;                                             \
-        const int colc_ = min(col_, w - 1);                                              \
-        _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                 \
-            const int row_ = r0 + tr + 2 * j;                                            \
-            const size_t at_ = (size_t)min(row_, h - 1) * w + colc_;                     \
-            const float pv_ = srcp[at_];                                                 \
-            const float qv_ = srcq[at_];                                                 \
-            const float v_ = prod ? pv_ * qv_ : pv_;                                     \
+
+    const int nfull = w / RG_TILE;                        // tiles that lie wholly inside the row
+    const int ntiles = (w + (RG_N - 1) + RG_TILE - 1) / RG_TILE;  // m = n + 4 runs to w + 3
+    float nxt[RG_TILE];
+    // tile T of this lane's row into nxt[]: whole tiles as 16-byte loads, the rest element-wise
+#define RG_LOAD_TILE(T)                                                                   \
+    if ((T) < nfull) {                                                                    \
+        const rg_f4* p4_ = reinterpret_cast<const rg_f4*>(srcp + (size_t)(T) * RG_TILE);  \
+        const rg_f4* q4_ = reinterpret_cast<const rg_f4*>(srcq + (size_t)(T) * RG_TILE);  \
+        _Pragma("unroll") for (int v = 0; v < RG_TILE / 4; ++v) {                         \
+            rg_f4 pv_, qv_;                                                               \
+            __builtin_memcpy(&pv_, p4_ + v, 16);                                          \
+            __builtin_memcpy(&qv_, q4_ + v, 16);                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                 \
+                nxt[4 * v + e] = prod ? pv_[e] * qv_[e] : pv_[e];                         \
+        }                                                                                 \
+    } else {                                                                              \
+        _Pragma("unroll") for (int mm = 0; mm < RG_TILE; ++mm) {                          \
+            const int col_ = (T) * RG_TILE + mm;                                          \
+            const int colc_ = min(col_, w - 1);                                           \
+            const float pv_ = srcp[colc_], qv_ = srcq[colc_];                             \
             /* x * 1 and x * 0 are exact for the finite, non-negative XYB values; a select */ \
-            /* here is turned into a branch around the load, one wait per load */       \
-            nxt[j] = v_ * ((col_ < w && row_ < h) ? 1.0f : 0.0f);                        \
-        }                                                                                \
+            /* here is turned into a branch around the load, one wait per load */        \
+            nxt[mm] = (prod ? pv_ * qv_ : pv_) * (col_ < w ? 1.0f : 0.0f);               \
+        }                                                                                 \
     }
     RG_LOAD_TILE(0)
-    for (int t = 0; t <= ntiles; ++t) {
-        if (t < ntiles) {
-            // tile t into the ring; zero beyond the line's end (the published zero padding)
-            const int slot = (t * RG_TILE + tc) & (RG_RING - 1);
+    for (int t = 0; t < ntiles; ++t) {
+        float r[RG_TILE];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) s_in[tr + 2 * j][slot] = nxt[j];
-        }
-        __syncthreads();
+        for (int mm = 0; mm < RG_TILE; ++mm) r[mm] = nxt[mm];
         if (t + 1 < ntiles) RG_LOAD_TILE(t + 1)
-        if (t < ntiles) {
-            // 32 steps of this lane's row: m = right-hand input column, output column m - 4.  The
-            // tile's 32 inputs are fetched from LDS in one batch; the left-hand input in[m - 10] is
-            // the right-hand one of ten steps ago and stays in registers (prev = the last ten of
-            // the previous tile; zeros before the line starts, the published padding).
-            float r[RG_TILE];
+        // 32 steps: m = 32 t + mm is the right-hand input column, the output column is m - 4, so
+        // the tile's outputs are columns 32 t - 4 .. 32 t + 27.
+        float o[RG_TILE];
 #pragma unroll
-            for (int mm = 0; mm < RG_TILE; ++mm) r[mm] = s_in[lane][(t * RG_TILE + mm) & (RG_RING - 1)];
-#pragma unroll
-            for (int mm = 0; mm < RG_TILE; ++mm) {
-                const float left = mm >= 2 * RG_N ? r[mm - 2 * RG_N] : prev[mm];
-                const float o = rg_step<FMA>(st, left, r[mm], n2, d1);
-                if (t > 0 || mm >= RG_N - 1)  // uniform: the first four steps produce no output
-                    s_out[lane][(t * RG_TILE + mm - (RG_N - 1)) & (RG_RING - 1)] = o;
-            }
-#pragma unroll
-            for (int k = 0; k < 2 * RG_N; ++k) prev[k] = r[RG_TILE - 2 * RG_N + k];
+        for (int mm = 0; mm < RG_TILE; ++mm) {
+            const float left = mm >= 2 * RG_N ? r[mm - 2 * RG_N] : prev[mm];
+            o[mm] = rg_step<FMA>(st, left, r[mm], n2, d1);
         }
-        __syncthreads();
-        // after tile t the outputs of columns < 32 t + 28 exist: flush output tile t - 1
-        if (t >= 1) {
-            const int col = (t - 1) * RG_TILE + tc;
-            if (col < w) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    const int row = r0 + tr + 2 * j;
-                    if (row < h) out[(size_t)row * w + col] = s_out[tr + 2 * j][col & (RG_RING - 1)];
+        for (int k = 0; k < 2 * RG_N; ++k) prev[k] = r[RG_TILE - 2 * RG_N + k];
+        // o[] = output columns c0 .. c0 + 31 with c0 = 32 t - 4 (a multiple of 4: 16-byte stores)
+        if (live) {
+            const int c0 = t * RG_TILE - (RG_N - 1);  // first output column of this tile's o[]
+            if (c0 >= 0 && c0 + RG_TILE <= w) {
+                rg_f4* o4 = reinterpret_cast<rg_f4*>(out + c0);
+#pragma unroll
+                for (int v = 0; v < RG_TILE / 4; ++v) {
+                    const rg_f4 val = {o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
+                    __builtin_memcpy(o4 + v, &val, 16);
+                }
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < RG_TILE; ++mm) {
+                    const int col = c0 + mm;
+                    if (col >= 0 && col < w) out[col] = o[mm];
                 }
             }
         }

@@ -203,7 +203,7 @@ class Ssimu2:
 
     def set_blur(self, mode: int) -> None:
         """ssimu2_ctx_set_blur: _lib.BLUR_FIR (default, the fused 9-tap kernels) or
-        _lib.BLUR_RECURSIVE (the published recursion, operation for operation; ~11x slower at 4K)."""
+        _lib.BLUR_RECURSIVE (the published recursion, operation for operation; ~9x slower at 4K)."""
         rc = self._L.ssimu2_ctx_set_blur(self._ctx, int(mode))
         if rc != 0:
             self._raise(rc)

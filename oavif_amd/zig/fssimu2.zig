@@ -53,7 +53,7 @@ pub var cache_reference: bool = true;
 
 /// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur): `.fir`, the fused
 /// 9-tap kernels (default, what the benchmarks measure), or `.recursive`, the published recursive
-/// Gaussian operation for operation (about 11x slower at 4K, still under 2 ms per score).  The two
+/// Gaussian operation for operation (about 9x slower at 4K, 1.4 ms per score).  The two
 /// differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5 at 4K); which of
 /// them fssimu2 0.1.1 agrees with could not be checked where this shim was written.  Set before
 /// the first call.
