@@ -169,3 +169,27 @@ def test_fused_recursion_order_planes_and_scores(hip_lib, oracle, w, h):
         assert abs(unfused - oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR)) <= TOL_SCORE
         if min(w, h) >= 16:
             assert fused != unfused
+
+
+def test_recursive_planes_of_a_large_frame_cross_4_gib(irscorer, oracle):
+    """8192 x 4100 (33.6 Mpx): the recursive mode's plane set is 4.8 GB, so plane bases lie beyond
+    2^31 and 2^32 bytes -- every offset the kernels form must be 64-bit.  Three of the 15 planes
+    (first, middle, last) against the oracle's recursion, bit for bit."""
+    w, h = 8192, 4100
+    base = synth.make_ref(1024, 1025, 31)
+    ref = np.tile(base, (4, 8, 1))
+    dist = np.ascontiguousarray(ref[::-1, ::-1])     # any other frame of the same size
+    assert ref.shape == (h, w, 3)
+    irscorer.rg_stop_after_scale(0)
+    irscorer.compute_ssimu2(ref, dist)
+    got = irscorer.debug_download(5, 0, w, h)
+    irscorer.rg_stop_after_scale(-1)
+    lut = oracle.srgb_lut()
+    for c, k in ((0, 0), (1, 2), (2, 4)):
+        xa = oracle.linear_to_xyb(np.ascontiguousarray(lut[ref].transpose(2, 0, 1)))[c]
+        xb = oracle.linear_to_xyb(np.ascontiguousarray(lut[dist].transpose(2, 0, 1)))[c]
+        src = [xa, xb, xa * xa, xb * xb, xa * xb][k]
+        del xa, xb
+        exp = oracle.blur_plane(src, oracle.BLUR_IIR)
+        assert np.array_equal(got[5 * c + k].view(np.uint32), exp.view(np.uint32)), (c, k)
+        del src, exp
