@@ -350,6 +350,21 @@ def main() -> int:
             out["roofline"]["frac_of_measured_read_stream"] = round(achieved / stream_gbs, 4)
         except Exception as e:
             out["roofline"]["measured_read_stream_GBps"] = f"error: {e}"
+        # What the blur-pyramid roofline looks like when it is NOT fused away: the same marching
+        # body as a plain blur stage (k_ref_blur: positive-XYB planes of one frame in, one blurred
+        # plane per channel out, all six scales in one launch), rotating over 8 frames' plane sets
+        # (HBM-fed), algorithmic bytes = every plane element read once and written once.
+        try:
+            b_ms, b_bytes = iscorer.time_blur_stage_rotating([p[0] for p in ptrs[:8]], w, h, 48)
+            b_gbs = b_bytes / (b_ms * 1e-3) / 1e9
+            out["roofline"]["blur_stage_unfused"] = {
+                "kernel": "k_ref_blur (the marching body as a plain HBM-to-HBM blur stage, one plane per channel)",
+                "ms": round(b_ms, 5), "algorithmic_bytes": int(b_bytes), "achieved": round(b_gbs, 1),
+                "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4),
+                "note": "a blur pyramid built from such HBM-to-HBM stages would show 2-3x the roofline fraction of "
+                        "the fused kernel and take ~5x its time; k_march keeps the 15 blurred planes in registers"}
+        except Exception as e:
+            out["roofline"]["blur_stage_unfused"] = f"error: {e}"
         # what actually bounds the kernel: VALU issue.  Instruction count from this round's PMC
         # run; two peaks: the nominal one (a wave64 VALU instruction per 2 cycles at 2.4 GHz) and
         # the one a plain v_mul/v_add stream reaches on this chip at 8 waves per SIMD.

@@ -67,6 +67,12 @@ int ssimu2_measure_read_stream(ssimu2_ctx* ctx, size_t bytes, int iters, double*
    ssimu2_set_reference also caches blur(ref*ref). */
 int ssimu2_instr_set_segment_rows(ssimu2_ctx* ctx, int rows_scale0, int rows_other_scales);
 int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
+/* The marching body as a plain blur stage (k_ref_blur: XYB planes of one frame in, one blurred
+   plane per channel out, all scales in one launch) timed over `iters` launches rotating over the
+   plane sets of `nframes` device-resident RGB8 frames (HBM-fed).  *out_bytes_per_launch: the
+   algorithmic bytes of one launch (every plane element read once, written once). */
+int ssimu2_time_blur_stage_rotating(ssimu2_ctx* ctx, const void* const* d_frames, int nframes, uint32_t w,
+                                    uint32_t h, int iters, float* out_ms_avg, double* out_bytes_per_launch);
 /* recursive mode: process scales 0..scale only, so that scale's planes stay downloadable
    (the score of such a run is meaningless); negative = all scales again */
 int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* ctx, int scale);

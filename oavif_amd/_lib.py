@@ -73,7 +73,7 @@ class TQSpecStats(ctypes.Structure):
 INSTR_SYMBOLS = ("ssimu2_debug_download", "ssimu2_time_device", "ssimu2_time_stage",
                  "ssimu2_time_march_rotating", "ssimu2_measure_read_stream",
                  "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur",
-                 "ssimu2_instr_rg_stop_after_scale")
+                 "ssimu2_instr_rg_stop_after_scale", "ssimu2_time_blur_stage_rotating")
 
 TQ_MAX_FANOUT = 16
 BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
@@ -166,6 +166,8 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
             "ssimu2_instr_set_segment_rows": [vp, ci, ci],
             "ssimu2_instr_cache_reference_blur": [vp, ci],
             "ssimu2_instr_rg_stop_after_scale": [vp, ci],
+            "ssimu2_time_blur_stage_rotating": [vp, ctypes.POINTER(vp), ci, u32, u32, ci,
+                                                ctypes.POINTER(ctypes.c_float), f64p],
         }
         for name, argtypes in sigs.items():
             if hasattr(L, name):  # scripts/gpu_ab.py also binds older builds that lack some hooks

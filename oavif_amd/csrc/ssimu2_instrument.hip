@@ -233,6 +233,75 @@ int ssimu2_time_march_rotating(ssimu2_ctx* c, const void* const* d_refs, const v
     return SSIMU2_OK;
 }
 
+// The marching body as a PLAIN blur stage (k_ref_blur: positive-XYB planes of one frame in, one
+// blurred plane per channel out, all scales in one launch), rotating over `nframes` frames' plane
+// sets so that inputs and outputs come from / go to HBM, not the Infinity Cache.
+int ssimu2_time_blur_stage_rotating(ssimu2_ctx* c, const void* const* d_frames, int nframes, uint32_t w,
+                                    uint32_t h, int iters, float* out_ms_avg, double* out_bytes_per_launch) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!d_frames || nframes <= 0 || nframes > 16 || iters <= 0 || !out_ms_avg)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad frames/iters/out");
+    int rc = check_args(c, d_frames[0], d_frames[0], w, h);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_capacity(c, w, h))) return rc;
+    c->have_ref = false;
+    const Pyramid p = make_pyramid(w, h);
+    const size_t planes = xyb_off(p, p.nscales) + 4;  // floats of one plane set (all scales)
+    float* buf = nullptr;
+    hipError_t e = hipMalloc(&buf, (size_t)nframes * 2 * planes * sizeof(float));
+    if (e != hipSuccess) return c->fail(SSIMU2_ERR_OOM, "hipMalloc(rotating blur-stage planes)", e);
+    MarchPlan* plans = new (std::nothrow) MarchPlan[nframes];
+    if (!plans) {
+        (void)hipFree(buf);
+        return c->fail(SSIMU2_ERR_OOM, "plans");
+    }
+    int blocks = 0;
+    for (int i = 0; i < nframes; ++i) {
+        const uint8_t* f = (const uint8_t*)d_frames[i];
+        float* xyb = buf + (size_t)(2 * i) * planes;
+        float* blur = buf + (size_t)(2 * i + 1) * planes;
+        if (p.nscales > 1) {
+            const uint8_t* frames[1] = {f};
+            float* lins[1] = {c->d_lin_ref};
+            launch_pyramid(c, p, 1, frames, lins);
+        }
+        for (int sc = 0; sc < p.nscales; ++sc) {
+            const size_t n = (size_t)p.w[sc] * p.h[sc];
+            const void* in = sc == 0 ? (const void*)f : (const void*)(c->d_lin_ref + p.lin_off[sc]);
+            hipLaunchKernelGGL(k_ref_xyb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, sc == 0,
+                               p.w[sc], p.h[sc], xyb + xyb_off(p, sc));
+        }
+        FinalizeArgs fa;
+        build_plans(c, p, f, f, false, &plans[i], &fa, &blocks);
+        for (int sc = 0; sc < p.nscales; ++sc) {
+            plans[i].dist[sc] = plans[i].ref[sc];
+            plans[i].ref_xyb[sc] = xyb + xyb_off(p, sc);
+            plans[i].ref_s11[sc] = blur + xyb_off(p, sc);
+        }
+    }
+    float ms = 0.f;
+    if (blocks > 0) {
+        for (int j = 0; j < 64; ++j)  // clocks (see ssimu2_time_march_rotating)
+            hipLaunchKernelGGL(k_ref_blur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, plans[j % nframes]);
+        e = hipEventRecord(c->ev0, c->stream);
+        for (int j = 0; j < iters && e == hipSuccess; ++j)
+            hipLaunchKernelGGL(k_ref_blur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, plans[j % nframes]);
+        if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    delete[] plans;
+    (void)hipFree(buf);
+    if (e != hipSuccess) return c->fail(SSIMU2_ERR_HIP, "rotating blur-stage timing", e);
+    *out_ms_avg = ms / (float)iters;
+    // algorithmic bytes of one launch: every plane element read once and written once
+    if (out_bytes_per_launch) *out_bytes_per_launch = 2.0 * (double)xyb_off(p, p.nscales) * sizeof(float);
+    return SSIMU2_OK;
+}
+
 int ssimu2_measure_read_stream(ssimu2_ctx* c, size_t bytes, int iters, double* out_gbps) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
     if (bytes < (1u << 20) || iters <= 0 || !out_gbps)

@@ -246,6 +246,20 @@ class Ssimu2:
             self._raise(rc)
         return ms.value
 
+    def time_blur_stage_rotating(self, d_frames, w: int, h: int, iters: int):
+        """-> (average device ms, algorithmic bytes per launch) of k_ref_blur -- the marching body as a
+        plain blur stage: XYB planes of one frame in, one blurred plane per channel out -- over
+        `iters` launches rotating over the plane sets of the device-resident frames (HBM-fed)."""
+        self._need_instr()
+        n = len(d_frames)
+        arr = ctypes.c_void_p * n
+        ms, nbytes = ctypes.c_float(), ctypes.c_double()
+        rc = self._L.ssimu2_time_blur_stage_rotating(self._ctx, arr(*d_frames), n, w, h, iters,
+                                                     ctypes.byref(ms), ctypes.byref(nbytes))
+        if rc != 0:
+            self._raise(rc)
+        return ms.value, nbytes.value
+
     def set_segment_rows(self, rows_scale0: int, rows_other_scales: int) -> None:
         self._need_instr()
         rc = self._L.ssimu2_instr_set_segment_rows(self._ctx, rows_scale0, rows_other_scales)
