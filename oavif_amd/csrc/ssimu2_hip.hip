@@ -146,11 +146,15 @@ struct ssimu2_ctx {
     size_t cap_stage = 0;
     size_t cap_xyb = 0;
     double* d_partials = nullptr;
-    // SSIMU2_BLUR_RECURSIVE only (ssimu2_recursive.h): XYB of both frames + 15 + 15 blurred planes of one scale
+    // SSIMU2_BLUR_RECURSIVE only (ssimu2_recursive.h), every scale packed: XYB planes of both frames
+    // [3], the reference's cached mu1 / s11 planes [6], the horizontal pass of a pass's planes [9]
     int blur_mode = SSIMU2_BLUR_FIR;
     float* d_rg = nullptr;
     size_t cap_rg = 0;            // floats
-    double* d_rg_part = nullptr;  // [scale][18][RG_MAPS_BLOCKS]
+    double* d_rg_part = nullptr;  // [scale][18][column groups]
+    size_t cap_rg_part = 0;       // doubles
+    float* d_rg_dbg = nullptr;    // instrumented builds: 15 + 15 raw planes of scale rg_dbg_scale
+    size_t cap_rg_dbg = 0;
     double* d_result = nullptr;   // 110 doubles
     double* h_result = nullptr;   // pinned mirror
 
@@ -164,7 +168,7 @@ struct ssimu2_ctx {
     int seg_rows_override = 0;
     int seg_rows_tail_override = 0;
     bool cache_ref_blur = true;
-    int rg_stop_after_scale = kNumScales;  // recursive mode: leave that scale's planes in d_rg
+    int rg_dbg_scale = -1;  // recursive mode: keep that scale's 15 raw planes (after each pass) downloadable
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
@@ -245,6 +249,15 @@ size_t partial_doubles(const ssimu2_ctx* c, const Pyramid& p) {
     return t;
 }
 
+void free_recursive(ssimu2_ctx* c) {
+    (void)hipFree(c->d_rg);
+    (void)hipFree(c->d_rg_part);
+    (void)hipFree(c->d_rg_dbg);
+    c->d_rg = c->d_rg_dbg = nullptr;
+    c->d_rg_part = nullptr;
+    c->cap_rg = c->cap_rg_part = c->cap_rg_dbg = 0;
+}
+
 void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_ref_u8);
     (void)hipFree(c->d_dist_u8);
@@ -260,11 +273,7 @@ void free_buffers(ssimu2_ctx* c) {
     (void)hipFree(c->d_ref_blur);
     c->d_ref_blur = nullptr;
     c->cap_blur = 0;
-    (void)hipFree(c->d_rg);
-    (void)hipFree(c->d_rg_part);
-    c->d_rg = nullptr;
-    c->d_rg_part = nullptr;
-    c->cap_rg = 0;
+    free_recursive(c);
     c->d_ref_u8 = c->d_dist_u8 = nullptr;
     c->d_lin_ref = c->d_lin_dist = nullptr;
     c->d_partials = nullptr;
@@ -364,62 +373,167 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
     *total_blocks = blocks;
 }
 
-// The published-recursion mode (ssimu2_recursive.h): per scale XYB of both frames, horizontal and
-// vertical recursive passes of the 15 planes, maps; the linear pyramids are already enqueued.
-int enqueue_recursive(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, const uint8_t* d_dist) {
-    const size_t n0 = (size_t)p.w[0] * p.h[0];
-    const size_t need = 36 * n0;
-    if (need > c->cap_rg) {
+// ---- the published-recursion modes (ssimu2_recursive.h) ------------------------------------------
+// plane offset (floats per plane) of scale s in the packed recursive-mode buffers
+size_t rg_plane_off(const Pyramid& p, int s) {
+    size_t off = 0;
+    for (int k = 0; k < s; ++k) off += (size_t)p.w[k] * p.h[k];
+    return off;
+}
+
+constexpr uint64_t kRgMaxPixels = 1ull << 28;  // 21 planes of 1.33 n floats: 30 GB at this size
+
+int rg_check_size(ssimu2_ctx* c, uint32_t w, uint32_t h) {
+    if ((uint64_t)w * h > kRgMaxPixels)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive blur mode: image larger than 2^28 pixels");
+    return SSIMU2_OK;
+}
+
+// Scratch + cache of the recursive modes for this frame size.  Growing drops a cached reference
+// (its planes live here).
+int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
+    const size_t ntot = rg_plane_off(p, p.nscales);
+    const size_t need = 21 * ntot + (size_t)p.w[0] + 16;  // + the dump row of k_rg_v_emit
+    size_t need_part = 8;
+    for (int s = 0; s < p.nscales; ++s) need_part += (size_t)kStats * ((p.w[s] + RG_VW - 1) / RG_VW);
+    if (need > c->cap_rg || need_part > c->cap_rg_part) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_rg);
+        (void)hipFree(c->d_rg_part);
         c->d_rg = nullptr;
-        c->cap_rg = 0;
-        const hipError_t e = hipMalloc(&c->d_rg, need * sizeof(float));
+        c->d_rg_part = nullptr;
+        c->cap_rg = c->cap_rg_part = 0;
+        c->have_ref = false;
+        hipError_t e = hipMalloc(&c->d_rg, need * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&c->d_rg_part, need_part * sizeof(double));
         if (e != hipSuccess) {
+            (void)hipFree(c->d_rg);
             c->d_rg = nullptr;
-            return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur planes: 144 bytes per pixel)", e);
+            c->d_rg_part = nullptr;
+            return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur planes: 84 bytes per pixel and scale)", e);
         }
         c->cap_rg = need;
+        c->cap_rg_part = need_part;
     }
-    if (!c->d_rg_part) {
-        const hipError_t e = hipMalloc(&c->d_rg_part, sizeof(double) * kNumScales * kStats * RG_MAPS_BLOCKS);
-        if (e != hipSuccess) {
-            c->d_rg_part = nullptr;
-            return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur partial sums)", e);
+    if (c->rg_dbg_scale >= 0 && c->rg_dbg_scale < p.nscales) {
+        const size_t nd = (size_t)24 * p.w[c->rg_dbg_scale] * p.h[c->rg_dbg_scale] + 16;  // 15 h planes + 9 v planes
+        if (nd > c->cap_rg_dbg) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_rg_dbg);
+            c->d_rg_dbg = nullptr;
+            c->cap_rg_dbg = 0;
+            const hipError_t e = hipMalloc(&c->d_rg_dbg, nd * sizeof(float));
+            if (e != hipSuccess) {
+                c->d_rg_dbg = nullptr;
+                return c->fail(SSIMU2_ERR_OOM, "hipMalloc(recursive-blur debug planes)", e);
+            }
+            c->cap_rg_dbg = nd;
+        }
+    }
+    return SSIMU2_OK;
+}
+
+// Plan of one frame's share of a recursive-mode score: `ref_frame` selects the reference's
+// buffers (XYB out = xa, linear pyramid = d_lin_ref) or the distorted frame's.
+void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, bool ref_frame, RgPlan* rp,
+                   int* xblocks, int* hblocks, int* vblocks) {
+    memset(rp, 0, sizeof *rp);
+    const size_t ntot = rg_plane_off(p, p.nscales);
+    float* xa = c->d_rg;
+    float* xb = xa + 3 * ntot;
+    float* cache = xb + 3 * ntot;
+    float* hbuf = cache + 6 * ntot;
+    rp->nscales = p.nscales;
+    int xb_ = 0, hb_ = 0, vb_ = 0;
+    size_t poff = 0;
+    for (int s = 0; s < p.nscales; ++s) {
+        const size_t n = (size_t)p.w[s] * p.h[s], off = rg_plane_off(p, s);
+        rp->w[s] = p.w[s];
+        rp->h[s] = p.h[s];
+        xb_ += (int)((n + 255) / 256);
+        hb_ += 3 * ((p.h[s] + RG_HL - 1) / RG_HL);
+        rp->vgroups[s] = (p.w[s] + RG_VW - 1) / RG_VW;
+        vb_ += 3 * rp->vgroups[s];
+        rp->xblk_end[s] = xb_;
+        rp->hblk_end[s] = hb_;
+        rp->vblk_end[s] = vb_;
+        const float* lin = (ref_frame ? c->d_lin_ref : c->d_lin_dist) + p.lin_off[s];
+        rp->lin[s] = s == 0 ? (const void*)d_frame : (const void*)lin;
+        rp->xa[s] = xa + 3 * off;
+        rp->xb[s] = xb + 3 * off;
+        rp->xout[s] = (ref_frame ? xa : xb) + 3 * off;
+        rp->cache[s] = cache + 6 * off;
+        rp->hbuf[s] = hbuf + 9 * off;
+        rp->part[s] = c->d_rg_part + poff;
+        poff += (size_t)kStats * rp->vgroups[s];
+    }
+    rp->dump = hbuf + 9 * ntot;
+    *xblocks = xb_;
+    *hblocks = hb_;
+    *vblocks = vb_;
+}
+
+// Instrumented builds (ssimu2_instr_rg_stop_after_scale): keep the raw planes of one scale for the
+// parity tests.  After a horizontal pass its planes are copied out of hbuf; the per-pass planes of
+// the vertical pass exist only in LDS, so k_rg_v_emit recomputes them into the debug buffer.
+bool rg_debugging(const ssimu2_ctx* c, const Pyramid& p) {
+    return c->d_rg_dbg && c->rg_dbg_scale >= 0 && c->rg_dbg_scale < p.nscales;
+}
+
+void rg_debug_keep_h(ssimu2_ctx* c, const Pyramid& p, const RgPlan& rp, bool ref) {
+    const int s = c->rg_dbg_scale, nk = ref ? 2 : 3;
+    const size_t n = (size_t)p.w[s] * p.h[s];
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < nk; ++k)
+            (void)hipMemcpyAsync(c->d_rg_dbg + (size_t)rg_plane15(ref, ch, k) * n, rp.hbuf[s] + (size_t)(ch * nk + k) * n,
+                                 n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+}
+
+// What depends on the reference alone: its XYB planes and mu1 = blur(x), s11 = blur(x * x) at
+// every scale (the reference's linear pyramid is already enqueued).
+void rg_enqueue_reference(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref) {
+    RgPlan rp;
+    int xblocks, hblocks, vblocks;
+    rg_build_plan(c, p, d_ref, true, &rp, &xblocks, &hblocks, &vblocks);
+    if (xblocks == 0) return;  // a frame below 8 x 8 has no scale to score
+    for (int s = 0; s < p.nscales; ++s) rp.emit[s] = rp.cache[s];
+    const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
+    hipLaunchKernelGGL(k_rg_xyb, dim3(xblocks), dim3(256), 0, c->stream, rp);
+    if (fma) hipLaunchKernelGGL((k_rg_h<true, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
+    else hipLaunchKernelGGL((k_rg_h<false, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
+    if (dbg) rg_debug_keep_h(c, p, rp, true);
+    if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
+    else hipLaunchKernelGGL((k_rg_v_emit<false, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
+}
+
+// One pass against the reference planes in place: XYB of the distorted frame, the recursion over
+// {y, y*y, x*y}, maps, final reduction (its linear pyramid is already enqueued).
+int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
+    RgPlan rp;
+    int xblocks, hblocks, vblocks;
+    rg_build_plan(c, p, d_dist, false, &rp, &xblocks, &hblocks, &vblocks);
+    const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
+    if (xblocks > 0) {  // a frame below 8 x 8 has no scale to score
+        hipLaunchKernelGGL(k_rg_xyb, dim3(xblocks), dim3(256), 0, c->stream, rp);
+        if (fma) hipLaunchKernelGGL((k_rg_h<true, false>), dim3(hblocks), dim3(192), 0, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_h<false, false>), dim3(hblocks), dim3(192), 0, c->stream, rp);
+        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vblocks), dim3(512), 0, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vblocks), dim3(512), 0, c->stream, rp);
+        if (dbg) {
+            rg_debug_keep_h(c, p, rp, false);
+            const int s = c->rg_dbg_scale;
+            rp.emit[s] = c->d_rg_dbg + (size_t)15 * p.w[s] * p.h[s];  // [channel][{y, yy, xy}][n]
+            if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
+            else hipLaunchKernelGGL((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
         }
     }
     FinalizeArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.nscales = p.nscales;
-    for (int s = 0; s < p.nscales && s <= c->rg_stop_after_scale; ++s) {
-        const int w = p.w[s], h = p.h[s];
-        const size_t n = (size_t)w * h;
-        RgArgs a;
-        float* xa = c->d_rg;
-        float* xb = xa + 3 * n0;
-        a.xa = xa;
-        a.xb = xb;
-        a.hout = xb + 3 * n0;
-        a.vout = a.hout + 15 * n0;
-        a.w = w;
-        a.h = h;
-        const void* in_a = s == 0 ? (const void*)d_ref : (const void*)(c->d_lin_ref + p.lin_off[s]);
-        const void* in_b = s == 0 ? (const void*)d_dist : (const void*)(c->d_lin_dist + p.lin_off[s]);
-        const unsigned xyb_blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_a, s == 0, w, h, xa);
-        hipLaunchKernelGGL(k_ref_xyb, dim3(xyb_blocks), dim3(256), 0, c->stream, in_b, s == 0, w, h, xb);
-        if (c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA) {
-            hipLaunchKernelGGL(k_rg_h<true>, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
-            hipLaunchKernelGGL(k_rg_v<true>, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
-        } else {
-            hipLaunchKernelGGL(k_rg_h<false>, dim3((h + 63) / 64, 15), dim3(64), 0, c->stream, a);
-            hipLaunchKernelGGL(k_rg_v<false>, dim3((w + 63) / 64, 15), dim3(64), 0, c->stream, a);
-        }
-        double* part = c->d_rg_part + (size_t)s * kStats * RG_MAPS_BLOCKS;
-        hipLaunchKernelGGL(k_rg_maps, dim3(RG_MAPS_BLOCKS, 3), dim3(256), 0, c->stream, a, part);
-        fa.part[s] = part;
-        fa.nblocks[s] = RG_MAPS_BLOCKS;
-        fa.inv_pixels[s] = 1.0 / ((double)w * (double)h);
+    for (int s = 0; s < p.nscales; ++s) {
+        fa.part[s] = rp.part[s];
+        fa.nblocks[s] = rp.vgroups[s];
+        fa.inv_pixels[s] = 1.0 / ((double)p.w[s] * (double)p.h[s]);
     }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
     HIP_TRY(c, hipGetLastError());
@@ -433,6 +547,15 @@ int enqueue_recursive(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, con
 int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, uint32_t w,
                   uint32_t h, bool ref_pyramid_ready) {
     const Pyramid p = make_pyramid(w, h);
+    const bool recursive = c->blur_mode != SSIMU2_BLUR_FIR;
+    if (recursive) {  // before anything is enqueued
+        int rc = rg_check_size(c, w, h);
+        if (rc) return rc;
+        const bool had_ref = c->have_ref;
+        if ((rc = rg_ensure(c, p))) return rc;
+        if (ref_pyramid_ready && had_ref && !c->have_ref)
+            return c->fail(SSIMU2_ERR_NO_REFERENCE, "recursive blur mode: the cached reference was dropped");
+    }
     if (p.nscales > 1) {
         if (ref_pyramid_ready) {
             const uint8_t* frames[1] = {d_dist};
@@ -444,10 +567,9 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
             launch_pyramid(c, p, 2, frames, lin);
         }
     }
-    if (c->blur_mode != SSIMU2_BLUR_FIR) {
-        if ((uint64_t)w * h > (1ull << 28))
-            return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive blur mode: image larger than 2^28 pixels");
-        return enqueue_recursive(c, p, d_ref, d_dist);
+    if (recursive) {
+        if (!ref_pyramid_ready) rg_enqueue_reference(c, p, d_ref);
+        return rg_enqueue_pass(c, p, d_dist);
     }
     MarchPlan mp;
     FinalizeArgs fa;
@@ -487,6 +609,11 @@ int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
     if (mode != SSIMU2_BLUR_FIR && mode != SSIMU2_BLUR_RECURSIVE && mode != SSIMU2_BLUR_RECURSIVE_FMA)
         return c->fail(SSIMU2_ERR_INVALID_ARG, "unknown blur mode");
     if (c->pending) return c->fail(SSIMU2_ERR_INVALID_ARG, "ssimu2_ctx_set_blur: a score is still enqueued");
+    if (mode == SSIMU2_BLUR_FIR && c->d_rg) {  // the recursive modes' planes are of no use to the default mode
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        free_recursive(c);
+    }
     c->blur_mode = mode;
     c->have_ref = false;
     return SSIMU2_OK;
@@ -670,15 +797,21 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_capacity(c, w, h))) return rc;
+    const Pyramid p = make_pyramid(w, h);
+    if (c->blur_mode != SSIMU2_BLUR_FIR) {  // size limit and planes of the recursive modes, before any launch
+        if ((rc = rg_check_size(c, w, h))) return rc;
+        if ((rc = rg_ensure(c, p))) return rc;
+    }
+    c->have_ref = false;
     const size_t bytes = (size_t)w * h * 3;
     HIP_TRY(c, hipMemcpyAsync(c->d_ref_u8, ref, bytes, kind, c->stream));
-    const Pyramid p = make_pyramid(w, h);
     if (p.nscales > 1) {  // the reference's linear pyramid, once per search
         const uint8_t* frames[1] = {c->d_ref_u8};
         float* lin[1] = {c->d_lin_ref};
         launch_pyramid(c, p, 1, frames, lin);
     }
-    if (c->blur_mode != SSIMU2_BLUR_FIR) {  // the recursive modes cache the pyramid only
+    if (c->blur_mode != SSIMU2_BLUR_FIR) {  // XYB planes, blur(x) and blur(x*x) by the published recursion
+        rg_enqueue_reference(c, p, c->d_ref_u8);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `ref` after return
         c->have_ref = true;

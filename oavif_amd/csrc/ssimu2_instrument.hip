@@ -58,7 +58,7 @@ int ssimu2_instr_set_segment_rows(ssimu2_ctx* c, int rows_scale0, int rows_other
 
 int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* c, int scale) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
-    c->rg_stop_after_scale = scale < 0 ? kNumScales : scale;
+    c->rg_dbg_scale = scale < 0 || scale >= kNumScales ? -1 : scale;
     return SSIMU2_OK;
 }
 
@@ -83,14 +83,28 @@ int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32
             return c->fail(SSIMU2_ERR_INVALID_ARG, "no cached reference XYB for that level");
         src = c->d_xyb_ref + xyb_off(p, scale);
     } else if (what == SSIMU2_DEBUG_RG_H || what == SSIMU2_DEBUG_RG_V) {
-        // 15 planes of the scale the recursive mode processed last (ssimu2_instr_rg_stop_after_scale)
-        if (scale < 0 || scale >= p.nscales || !c->d_rg) return c->fail(SSIMU2_ERR_INVALID_ARG, "no recursive-blur planes");
-        const size_t n0 = (size_t)p.w[0] * p.h[0];
-        if (36 * n0 > c->cap_rg) return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive-blur planes are of another frame size");
+        // 15 raw planes of the scale selected with ssimu2_instr_rg_stop_after_scale before the score
+        if (scale < 0 || scale >= p.nscales || scale != c->rg_dbg_scale || !c->d_rg_dbg || !c->d_rg)
+            return c->fail(SSIMU2_ERR_INVALID_ARG, "no recursive-blur planes kept for that scale");
+        const size_t n1 = (size_t)p.w[scale] * p.h[scale];
+        if (24 * n1 > c->cap_rg_dbg) return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive-blur planes are of another frame size");
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const float* src15 = c->d_rg + 6 * n0 + (what == SSIMU2_DEBUG_RG_V ? 15 * n0 : 0);
-        HIP_TRY(c, hipMemcpy(out, src15, (size_t)15 * p.w[scale] * p.h[scale] * sizeof(float), hipMemcpyDeviceToHost));
+        if (what == SSIMU2_DEBUG_RG_H) {
+            HIP_TRY(c, hipMemcpy(out, c->d_rg_dbg, 15 * n1 * sizeof(float), hipMemcpyDeviceToHost));
+        } else {
+            // x, xx: the reference cache [channel][{mu1, s11}]; y, yy, xy: k_rg_v_emit's planes
+            const float* cache = c->d_rg + 6 * rg_plane_off(p, p.nscales) + 6 * rg_plane_off(p, scale);
+            const float* pass = c->d_rg_dbg + 15 * n1;
+            for (int ch = 0; ch < 3; ++ch) {
+                for (int k = 0; k < 2; ++k)
+                    HIP_TRY(c, hipMemcpy(out + (size_t)rg_plane15(true, ch, k) * n1, cache + (size_t)(ch * 2 + k) * n1,
+                                         n1 * sizeof(float), hipMemcpyDeviceToHost));
+                for (int k = 0; k < 3; ++k)
+                    HIP_TRY(c, hipMemcpy(out + (size_t)rg_plane15(false, ch, k) * n1, pass + (size_t)(ch * 3 + k) * n1,
+                                         n1 * sizeof(float), hipMemcpyDeviceToHost));
+            }
+        }
         if (out_w) *out_w = (uint32_t)p.w[scale];
         if (out_h) *out_h = (uint32_t)p.h[scale];
         return SSIMU2_OK;

@@ -1,66 +1,109 @@
 // SSIMULACRA2 with the PUBLISHED blur: the recursive Gaussian of libjxl's ssimulacra2 (three
 // second-order sections driven by in[n-N-1] + in[n+N-1], N = 5 for sigma 1.5; Charalampidis 2016),
-// applied to the materialised product planes, horizontally then vertically -- the optional
-// SSIMU2_BLUR_RECURSIVE mode of a scorer context (include/ssimu2_hip.h).
+// applied to the materialised product planes, horizontally then vertically -- the
+// SSIMU2_BLUR_RECURSIVE / _FMA modes of a scorer context (include/ssimu2_hip.h).
 //
 // Why it exists: fssimu2's source is not available, the default kernels
 // evaluate the recursion's 9-tap impulse response instead (k_march), and the two differ by the
-// recursion's own rounding noise (median 0.5, up to 2.4 points at 4K).  This mode follows the
-// published operation order exactly -- the CPU checker's OR_BLUR_IIR planes are reproduced bit for
-// bit -- so a maintainer who can run fssimu2 can see which of the two it agrees with.
+// recursion's own rounding noise (median 0.5, up to 2.4 points at 4K).  This
+// mode follows the published operation order exactly -- the CPU checker's OR_BLUR_IIR planes are
+// reproduced bit for bit -- so whichever form fssimu2 follows can be had on the device.
 //
 // A recursion cannot be cut into strips or segments: every output depends on the whole line
-// before it.  Parallelism is therefore lines x planes only (15 planes per scale: x, y, xx, yy, xy
-// of three channels), ~1 wave per SIMD at 4K, each lane a chain of 2,160-3,840 dependent steps:
-// this mode is latency-bound by construction (about 9x the time of the default kernels at 4K)
-// and is not what `bench.py` measures.
+// before it, so the parallelism is lines x planes x sections and nothing else.  Round 3 layout
+// (all six scales in ONE launch per stage, largest scale first):
 //
-//   k_rg_h     lane = image row, streaming its own row 32 columns at a time as 16-byte loads and
-//              stores (no transposition, no LDS); the products are formed on load.
-//   k_rg_v     lane = image column: coalesced as it is; loads issued a batch of 10 rows ahead.
-//   k_rg_maps  SSIM and edge-difference maps from the 15 blurred planes + the two XYB frames,
-//              partial sums in the layout k_finalize reduces.
+//   k_rg_xyb   positive-XYB planes of one frame, every scale.
+//   k_rg_h     horizontal pass.  One LINE = THREE LANES, one second-order section each; the
+//              published sum (o1 + o3) + o5 is two DPP adds (row_shr:5) per step.  A wave holds
+//              4 DPP rows x 5 lines = 20 image rows (15 of 16 lanes busy); a workgroup is the
+//              planes of one channel over the same 20 rows, one wave per plane ({y, yy, xy} of
+//              a pass, {x, xx} of the reference), so the shared inputs are fetched once.  Each
+//              wave stages its 20 rows 64 columns at a time through wave-private LDS with coalesced
+//              16-byte loads and stores (see "Staging" below); products are formed on the way in,
+//              rounded to fp32 first as published.  8 VALU instructions per step instead of 15.
+//   k_rg_v     vertical pass + maps.  lane = image column (coalesced rows), the three sections in
+//              the lane; batches of ten rows, so that the left-hand inputs of a batch are the
+//              right-hand ones of the previous batch; loads two batches ahead.  The blurred
+//              rows go to a double-buffered LDS tile, where five more waves of the workgroup
+//              turn them -- with the cached reference planes -- into the SSIM / edge-difference
+//              sums (the expressions of k_march): the nine per-pass planes never reach HBM after
+//              the vertical pass.
+//   reference  mu1 = blur(x) and s11 = blur(x*x) depend on the reference alone (tq.zig:37 passes
+//              the same e.rgb on every pass): ssimu2_set_reference runs both passes over {x, xx}
+//              once and keeps the planes, so a pass of a search recurses 9 planes, not 15.
 #pragma once
 
 namespace ssimu2 {
 
-constexpr int RG_N = 5;                // radius of the sigma-1.5 recursion: round(3.2795 sigma + 0.2546)
-constexpr int RG_TILE = 32;            // columns per register tile of the horizontal pass
-constexpr int RG_MAPS_BLOCKS = 256;    // partial-sum blocks per scale and channel triple
+constexpr int RG_N = 5;         // radius of the sigma-1.5 recursion: round(3.2795 sigma + 0.2546)
+constexpr int RG_HL = 20;       // image rows per wave of the horizontal pass (4 DPP rows x 5 lines)
+constexpr int RG_HT = 16;       // columns per register tile of the horizontal pass
+constexpr int RG_VB = 2 * RG_N; // rows per batch of the vertical pass
+constexpr int RG_VW = 64;       // columns per workgroup of the vertical pass
+constexpr int RG_MAPS_WAVES = RG_VB / 2;  // each maps wave owns two rows of every batch
 
-struct RgArgs {
-    const float* xa;  // positive-XYB planes of the reference  [3][h][w]
-    const float* xb;  // ... of the distorted frame
-    float* hout;      // horizontal pass of the 15 planes     [15][h][w], plane = 5 * channel + kind
-    float* vout;      // vertical pass of those
-    int w, h;
+struct RgPlan {
+    int nscales;
+    int w[kNumScales], h[kNumScales];
+    int hblk_end[kNumScales];     // exclusive end of each scale's workgroups in the k_rg_h grid
+    int vblk_end[kNumScales];     // ... in the k_rg_v grid
+    int vgroups[kNumScales];      // column groups of a scale = partial sums per statistic
+    int xblk_end[kNumScales];     // ... in the k_rg_xyb grid
+    const void* lin[kNumScales];  // k_rg_xyb input: scale 0 tight RGB8, others fp32 linear planes [3][n]
+    float* xout[kNumScales];      // k_rg_xyb output [3][n]
+    const float* xa[kNumScales];  // positive-XYB planes of the reference [3][n]
+    const float* xb[kNumScales];  // ... of the distorted frame
+    float* hbuf[kNumScales];      // horizontal pass: [channel][plane of the pass][n]
+    float* cache[kNumScales];     // reference: [channel][{mu1, s11}][n]
+    double* part[kNumScales];     // [18 statistics][vgroups]
+    float* emit[kNumScales];      // k_rg_v_emit target [channel][plane of the pass][n]; null = skip the scale
+    float* dump;                  // one row of floats that absorbs the stores of rows outside the image
 };
 
-// kind: 0 = x, 1 = y, 2 = x*x, 3 = y*y, 4 = x*y (the product rounded to fp32 first, as published)
-__device__ __forceinline__ float rg_source(const float* a, const float* b, int kind, size_t i) {
-    if (kind == 0) return a[i];
-    if (kind == 1) return b[i];
-    if (kind == 2) {
-        const float v = a[i];
-        return v * v;
+// ---- XYB planes, every scale in one launch ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rg_xyb(RgPlan p) {
+    int sc = 0, first = 0;
+#pragma unroll
+    for (int s = 0; s < kNumScales - 1; ++s)
+        if (s + 1 < p.nscales && (int)blockIdx.x >= p.xblk_end[s]) {
+            sc = s + 1;
+            first = p.xblk_end[s];
+        }
+    const size_t n = (size_t)p.w[sc] * p.h[sc];
+    const size_t i = (size_t)((int)blockIdx.x - first) * 256 + threadIdx.x;
+    if (i >= n) return;
+    float r, g, b;
+    if (sc == 0) {
+        const uint8_t* q = (const uint8_t*)p.lin[0] + i * 3;
+        r = c_k.lut[q[0]];
+        g = c_k.lut[q[1]];
+        b = c_k.lut[q[2]];
+    } else {
+        const float* q = (const float*)p.lin[sc] + i;
+        r = q[0];
+        g = q[n];
+        b = q[2 * n];
     }
-    if (kind == 3) {
-        const float v = b[i];
-        return v * v;
-    }
-    return a[i] * b[i];
+    float X, Y, B;
+    linear_to_xyb(r, g, b, X, Y, B);
+    float* out = p.xout[sc];
+    out[i] = X;
+    out[n + i] = Y;
+    out[2 * n + i] = B;
 }
 
-// state of the three sections of one line
-struct RgState {
-    float p1[3], p2[3];  // previous and second-previous output of each section
-};
-
-// one step of the recursion (FastGaussian1D, scalar form):
+// ---- the recursion --------------------------------------------------------------------------------
+// one step (FastGaussian1D, scalar form):
 //   o_k = n2_k * (left + right) - prev2_k - d1_k * prev_k;   out = (o_1 + o_3) + o_5
 // FMA = false: every operation rounded by itself (the published scalar order);
 // FMA = true:  the last multiply-subtract fused, fma(-d1_k, prev_k, .), as a compiler targeting
 //              an FMA unit contracts it (SSIMU2_BLUR_RECURSIVE_FMA; the checker's OR_BLUR_IIR_FMA)
+
+// all three sections in one lane (vertical pass)
+struct RgState {
+    float p1[3], p2[3];  // previous and second-previous output of each section
+};
 template <bool FMA>
 __device__ __forceinline__ float rg_step(RgState& s, float left, float right, const float (&n2)[3],
                                          const float (&d1)[3]) {
@@ -79,193 +122,403 @@ __device__ __forceinline__ float rg_step(RgState& s, float left, float right, co
     return (o[0] + o[1]) + o[2];
 }
 
-// Horizontal pass.  One wave per (block of 64 rows, plane); grid = (ceil(h / 64), 15).
-// lane = image row, and the lane streams ITS OWN row: 32 columns per tile as eight 16-byte loads
-// (a lane's eight loads share one 128-byte line, the L1 serves the repeats) into registers, 32
-// recursion steps, eight 16-byte stores -- no transposition, no LDS, no barrier, one pointer per
-// lane.  The loads of tile t + 1 are issued before the steps of tile t (a lone wave per SIMD hides
-// nothing by itself).  The last, partial tile of a row goes element by element.
+// one section per lane, the sections of a line five lanes apart inside a 16-lane DPP row:
+// lanes 0-4 section 1, 5-9 section 3, 10-14 section 5 of lines 0-4; lane 15 idles.
+__device__ __forceinline__ float rg_shr5(float v) {  // value of the lane five below (same DPP row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x115, 0xf, 0xf, true));
+}
+// returns the line's output in the lanes of section 5 (10-14): (o1 + o3) + o5 in that order
+template <bool FMA>
+__device__ __forceinline__ float rg_step_lane(float& p1, float& p2, float left, float right, float n2, float d1) {
+    const float sum = left + right;
+    float v = sum * n2;
+    v = v - p2;
+    if (FMA) v = fmaf(-d1, p1, v);
+    else v = v - d1 * p1;
+    p2 = p1;
+    p1 = v;
+    const float t = rg_shr5(v) + v;  // lanes 5-9: o1 + o3
+    return rg_shr5(t) + v;           // lanes 10-14: (o1 + o3) + o5
+}
+
 typedef float rg_f4 __attribute__((ext_vector_type(4)));
 
-template <bool FMA>
-__global__ __launch_bounds__(64) void k_rg_h(RgArgs a) {
-    const int lane = threadIdx.x;
-    const int plane = blockIdx.y, ch = plane / 5, kind = plane - 5 * ch;
-    const int w = a.w, h = a.h;
-    const int row = blockIdx.x * 64 + lane;
-    const bool live = row < h;
+// Staging of the horizontal pass.  A lane that streamed its own row (round 2, and the first
+// round-3 form: 16-byte loads, 20 rows per wave) hands the memory pipeline one request PER LANE --
+// 64 tag look-ups per load instruction for 20 distinct 64-byte segments -- and the texture
+// addresser, not the recursion, set the time (k_rg_h 0.50 ms per 4K pass).  So a wave stages its 20
+// rows 64 columns at a time through wave-private LDS: five 16-byte loads per lane cover 20 rows x
+// 256 contiguous bytes (16 lanes per row: whole 64-byte segments per lane quad), one tile ahead of
+// its use; five ds_write_b128 put the tile into [row][column] order; each lane then reads its own
+// line 16 columns at a time (the three section lanes of a line read the same address: a
+// broadcast).  Outputs go back the same way: 16 columns per line into an LDS tile, five coalesced
+// 16-byte stores per 64 columns.  Wave-private LDS needs no barrier: the LDS executes one wave's
+// instructions in order; __builtin_amdgcn_wave_barrier() only stops the COMPILER from moving an
+// access across it (it cannot see that lanes read what other lanes wrote).
+constexpr int RG_TW = 64;          // columns per staged tile
+constexpr int RG_TP = RG_TW + 4;   // LDS row pitch in floats (16-byte multiple; spreads the rows over the banks)
+constexpr int RG_TR = RG_HL / 4;   // 16-byte accesses per lane and tile (4 rows of 16 lanes each)
+typedef float RgTile[RG_HL][RG_TP];
+
+struct RgLine {
+    const float* ga;        // plane(s) read (uniform)
+    const float* gb;
+    float* gout;            // plane written (uniform)
+    uint32_t goff[RG_TR];   // per lane: float offset of (row 4 i + lane / 16, column 4 (lane % 16)) in a plane
+    int w;
+    int line;               // this lane's line (0..19) and whether it holds the line's output (section 5)
+    bool holds_out;
+    float n2, d1;           // this lane's section
+    float p1, p2;           // ... and its state
+    float cur[2][RG_HT];    // inputs of the current and the previous 16-column group (by parity)
+};
+
+template <int OPK>
+__device__ __forceinline__ void rg_h_fetch(const RgLine& L, rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
+    // unconditional and all alike (countable by s_waitcnt vmcnt): a tile that reaches past the end
+    // of a row reads on into the next row / plane of the same allocation -- every plane read here
+    // is followed by other planes of the context's buffer -- and the EDGE tiles zero what lies
+    // outside the row
+#pragma unroll
+    for (int i = 0; i < RG_TR; ++i) {
+        __builtin_memcpy(&ra[i], L.ga + ((size_t)L.goff[i] + (size_t)T * RG_TW), 16);
+        if (OPK == 2) __builtin_memcpy(&rb[i], L.gb + ((size_t)L.goff[i] + (size_t)T * RG_TW), 16);
+    }
+}
+
+// Tile T of the line: 64 steps.  Step m has the right-hand input column m and the left-hand one
+// m - 10 and produces output column m - 4 (zeros outside the row: the published padding).
+// OPK: 0 = the plane itself, 1 = its square, 2 = the product of two planes (rounded to fp32 before
+// the blur, as published).  EDGE: the tile touches the row's first or last columns.
+template <bool FMA, int OPK, bool EDGE>
+__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgTile& tout,
+                                          rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
+    const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < RG_TR; ++i) {
+        *reinterpret_cast<rg_f4*>(&tin_a[4 * i + rr][4 * cc]) = ra[i];
+        if (OPK == 2) *reinterpret_cast<rg_f4*>(&tin_b[4 * i + rr][4 * cc]) = rb[i];
+    }
+    rg_h_fetch<OPK>(L, ra, rb, T + 1);  // lands under this tile's 64 steps
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < RG_TW / RG_HT; ++s) {
+        float (&c)[RG_HT] = L.cur[s & 1];
+        const float (&pv)[RG_HT] = L.cur[(s & 1) ^ 1];
+#pragma unroll
+        for (int v = 0; v < RG_HT / 4; ++v) {
+            const rg_f4 a = *reinterpret_cast<const rg_f4*>(&tin_a[L.line][RG_HT * s + 4 * v]);
+            rg_f4 b = a;
+            if (OPK == 2) b = *reinterpret_cast<const rg_f4*>(&tin_b[L.line][RG_HT * s + 4 * v]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[4 * v + e] = OPK == 0 ? a[e] : a[e] * b[e];
+        }
+        if (EDGE) {
+#pragma unroll
+            for (int mm = 0; mm < RG_HT; ++mm) c[mm] = T * RG_TW + RG_HT * s + mm < L.w ? c[mm] : 0.0f;
+        }
+        float o[RG_HT];
+#pragma unroll
+        for (int mm = 0; mm < RG_HT; ++mm) {
+            const float left = mm >= 2 * RG_N ? c[mm - 2 * RG_N] : pv[mm + RG_HT - 2 * RG_N];
+            o[mm] = rg_step_lane<FMA>(L.p1, L.p2, left, c[mm], L.n2, L.d1);
+        }
+        if (L.holds_out) {
+#pragma unroll
+            for (int v = 0; v < RG_HT / 4; ++v)
+                *reinterpret_cast<rg_f4*>(&tout[L.line][RG_HT * s + 4 * v]) =
+                    rg_f4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // tout = output columns 64 T - 4 .. 64 T + 59 of the 20 rows
+#pragma unroll
+    for (int i = 0; i < RG_TR; ++i) {
+        const rg_f4 v = *reinterpret_cast<const rg_f4*>(&tout[4 * i + rr][4 * cc]);
+        float* dst = L.gout + ((size_t)L.goff[i] + (size_t)T * RG_TW) - (RG_N - 1);
+        if (!EDGE) {
+            __builtin_memcpy(dst, &v, 16);
+        } else {
+            const int col = T * RG_TW - (RG_N - 1) + 4 * cc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e >= 0 && col + e < L.w) dst[e] = v[e];
+        }
+    }
+}
+
+template <bool FMA, int OPK>
+__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgTile& tout) {
+    const int w = L.w;
+    const int ntiles = (w + (RG_N - 1) + RG_TW - 1) / RG_TW;  // steps run to m = w + 3
+    const int nmain = max(1, w / RG_TW);                      // tiles 1 .. nmain - 1 touch no edge
+    rg_f4 ra[RG_TR], rb[RG_TR];
+#pragma unroll
+    for (int k = 0; k < RG_HT; ++k) L.cur[1][k] = 0.0f;  // columns -16 .. -1
+    L.p1 = L.p2 = 0.0f;
+    rg_h_fetch<OPK>(L, ra, rb, 0);
+    rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, ra, rb, 0);
+    int T = 1;
+#pragma unroll 1
+    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin_a, tin_b, tout, ra, rb, T);
+#pragma unroll 1
+    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, ra, rb, T);
+}
+
+// plane index among the 15 of a scale (5 * channel + {x, y, xx, yy, xy}) of plane `kind` of a pass
+__host__ __device__ __forceinline__ int rg_plane15(bool ref, int ch, int kind) {
+    return 5 * ch + (ref ? 2 * kind : (kind == 0 ? 1 : kind + 2));
+}
+
+// Horizontal pass.  REF: the planes {x, x*x} of the reference (once per search); otherwise
+// {y, y*y, x*y}.  grid = sum over scales of 3 channels x ceil(h / 20) workgroups of NK waves.
+template <bool FMA, bool REF>
+__global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {
+    constexpr int NK = REF ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) RgTile s_in[REF ? 2 : 4];
+    __shared__ __attribute__((aligned(16))) RgTile s_o[NK];
+    int sc = 0, first = 0;
+#pragma unroll
+    for (int s = 0; s < kNumScales - 1; ++s)
+        if (s + 1 < p.nscales && (int)blockIdx.x >= p.hblk_end[s]) {
+            sc = s + 1;
+            first = p.hblk_end[s];
+        }
+    const int blk = (int)blockIdx.x - first;
+    const int ch = blk % 3, rgrp = blk / 3;
+    const int kind = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int w = p.w[sc], h = p.h[sc];
     const size_t n = (size_t)w * h;
-    const size_t base = (size_t)min(row, h - 1) * w;  // idle lanes shadow the last row, never store
-    const float* xa = a.xa + ch * n;
-    const float* xb = a.xb + ch * n;
-    // plane kinds as a pointer pair and a uniform flag: x, y, x*x, y*y, x*y
-    const float* srcp = ((kind == 1 || kind == 3) ? xb : xa) + base;
-    const float* srcq = (kind == 2 ? xa : xb) + base;
-    const bool prod = kind >= 2;
-    float* out = a.hout + plane * n + base;
+    RgLine L;
+    // lane -> (DPP row, line, section); lane 15 of a row shadows line 4 / section 5 and holds nothing
+    const int l16 = lane & 15;
+    const int sec = l16 < 15 ? l16 / 5 : 2;
+    L.line = (lane >> 4) * 5 + (l16 < 15 ? l16 - 5 * sec : 4);
+    L.holds_out = l16 >= 10 && l16 < 15;
+    L.n2 = c_k.rg_n2[sec];
+    L.d1 = c_k.rg_d1[sec];
+    L.w = w;
+    // rows of the cooperative 16-byte accesses; rows behind the image shadow its last row (their
+    // lines compute and store that row's values once more)
+#pragma unroll
+    for (int i = 0; i < RG_TR; ++i)
+        L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)w + 4u * (uint32_t)(lane & 15);
+    const float* xa = p.xa[sc] + ch * n;
+    const float* xb = REF ? xa : p.xb[sc] + ch * n;
+    L.gout = p.hbuf[sc] + (size_t)(ch * NK + kind) * n;
+    // REF: x, x*x.  pass: y, y*y, x*y
+    L.ga = kind == 2 ? xa : xb;
+    L.gb = xb;
+    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_in[0], s_o[0]);
+    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_in[1], s_o[1]);
+    else rg_h_line<FMA, 2>(L, s_in[REF ? 0 : 2], s_in[REF ? 1 : 3], s_o[NK - 1]);
+}
+
+// ---- vertical pass (+ maps) -----------------------------------------------------------------------
+// The SSIM and edge-difference terms of one pixel from its five blurred values and the two frames
+// (the expressions of march_v; products rounded as there).
+__device__ __forceinline__ void rg_maps_pixel(float mu1, float mu2, float s11, float s22, float s12, float r1,
+                                              float r2, double (&acc)[6]) {
+    const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+    const float dm = mu1 - mu2;
+    const float num_m = fmaf(-dm, dm, 1.0f);
+    const float num_s = fmaf(2.0f, s12 - mu12, kC2);
+    const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
+    float d = 1.0f - div_rn(num_m * num_s, denom_s);
+    d = fmaxf(d, 0.0f);
+    const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
+    const float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
+    const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
+    const float d2 = d * d, a2 = art * art, t2 = det * det;
+    acc[0] += (double)d;
+    acc[1] += (double)(d2 * d2);
+    acc[2] += (double)art;
+    acc[3] += (double)(a2 * a2);
+    acc[4] += (double)det;
+    acc[5] += (double)(t2 * t2);
+}
+
+// The recursion of one plane down this lane's column, PF batches of ten rows in a register queue
+// (three in flight under the one consumed).  Everything that counts in vmcnt is unconditional:
+// rows behind the image load the last row (and are replaced by the published zero padding in the
+// steps), lanes right of the image shadow its last column, and the batch count is rounded up to
+// the queue depth (the batches behind the image produce nothing that is kept).  `emit(b, o)`
+// receives the ten outputs of batch b: rows 10 b - 4 .. 10 b + 5.
+constexpr int RG_PF = 4;
+__device__ __forceinline__ int rg_v_batches(int h) {
+    return ((h + (RG_N - 1) + RG_VB - 1) / RG_VB + RG_PF - 1) / RG_PF * RG_PF;  // step m = right-hand row, to h + 3
+}
+
+template <bool FMA, typename Emit>
+__device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w, int h, Emit emit) {
     const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
     const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
+    const int nb = rg_v_batches(h);
     RgState st;
 #pragma unroll
     for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
-    float prev[2 * RG_N];  // the last ten inputs of the previous tile (zeros: the published padding)
+    float q[RG_PF][RG_VB];  // queue slot b % PF holds rows 10 b .. 10 b + 9, as loaded
+#define RG_V_LOAD(B, SLOT)                                          \
+    _Pragma("unroll") for (int j = 0; j < RG_VB; ++j)               \
+        q[SLOT][j] = in[(size_t)min((B) * RG_VB + j, h - 1) * w];
 #pragma unroll
-    for (int k = 0; k < 2 * RG_N; ++k) prev[k] = 0.f;
-
-    const int nfull = w / RG_TILE;                        // tiles that lie wholly inside the row
-    const int ntiles = (w + (RG_N - 1) + RG_TILE - 1) / RG_TILE;  // m = n + 4 runs to w + 3
-    float nxt[RG_TILE];
-    // tile T of this lane's row into nxt[]: whole tiles as 16-byte loads, the rest element-wise
-#define RG_LOAD_TILE(T)                                                                   \
-    if ((T) < nfull) {                                                                    \
-        const rg_f4* p4_ = reinterpret_cast<const rg_f4*>(srcp + (size_t)(T) * RG_TILE);  \
-        const rg_f4* q4_ = reinterpret_cast<const rg_f4*>(srcq + (size_t)(T) * RG_TILE);  \
-        _Pragma("unroll") for (int v = 0; v < RG_TILE / 4; ++v) {                         \
-            rg_f4 pv_, qv_;                                                               \
-            __builtin_memcpy(&pv_, p4_ + v, 16);                                          \
-            __builtin_memcpy(&qv_, q4_ + v, 16);                                          \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                 \
-                nxt[4 * v + e] = prod ? pv_[e] * qv_[e] : pv_[e];                         \
-        }                                                                                 \
-    } else {                                                                              \
-        _Pragma("unroll") for (int mm = 0; mm < RG_TILE; ++mm) {                          \
-            const int col_ = (T) * RG_TILE + mm;                                          \
-            const int colc_ = min(col_, w - 1);                                           \
-            const float pv_ = srcp[colc_], qv_ = srcq[colc_];                             \
-            /* x * 1 and x * 0 are exact for the finite, non-negative XYB values; a select */ \
-            /* here is turned into a branch around the load, one wait per load */        \
-            nxt[mm] = (prod ? pv_ * qv_ : pv_) * (col_ < w ? 1.0f : 0.0f);               \
-        }                                                                                 \
-    }
-    RG_LOAD_TILE(0)
-    for (int t = 0; t < ntiles; ++t) {
-        float r[RG_TILE];
+    for (int j = 0; j < RG_VB; ++j) q[RG_PF - 1][j] = 0.f;  // batch -1: rows -10 .. -1
+    RG_V_LOAD(0, 0)
+    RG_V_LOAD(1, 1)
+    RG_V_LOAD(2, 2)
+#pragma unroll 1
+    for (int b0 = 0; b0 < nb; b0 += RG_PF) {
 #pragma unroll
-        for (int mm = 0; mm < RG_TILE; ++mm) r[mm] = nxt[mm];
-        if (t + 1 < ntiles) RG_LOAD_TILE(t + 1)
-        // 32 steps: m = 32 t + mm is the right-hand input column, the output column is m - 4, so
-        // the tile's outputs are columns 32 t - 4 .. 32 t + 27.
-        float o[RG_TILE];
+        for (int u = 0; u < RG_PF; ++u) {
+            const int b = b0 + u;
+            // the slot of batch b + 3 is the one batch b - 1 (this batch's left-hand inputs) sits
+            // in, so its loads are issued AFTER the steps
+            float (&right)[RG_VB] = q[u];
+            const float (&left)[RG_VB] = q[(u + RG_PF - 1) % RG_PF];
+            if (b * RG_VB + RG_VB > h) {  // uniform: the image ends inside or before this batch
 #pragma unroll
-        for (int mm = 0; mm < RG_TILE; ++mm) {
-            const float left = mm >= 2 * RG_N ? r[mm - 2 * RG_N] : prev[mm];
-            o[mm] = rg_step<FMA>(st, left, r[mm], n2, d1);
-        }
-#pragma unroll
-        for (int k = 0; k < 2 * RG_N; ++k) prev[k] = r[RG_TILE - 2 * RG_N + k];
-        // o[] = output columns c0 .. c0 + 31 with c0 = 32 t - 4 (a multiple of 4: 16-byte stores)
-        if (live) {
-            const int c0 = t * RG_TILE - (RG_N - 1);  // first output column of this tile's o[]
-            if (c0 >= 0 && c0 + RG_TILE <= w) {
-                rg_f4* o4 = reinterpret_cast<rg_f4*>(out + c0);
-#pragma unroll
-                for (int v = 0; v < RG_TILE / 4; ++v) {
-                    const rg_f4 val = {o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
-                    __builtin_memcpy(o4 + v, &val, 16);
-                }
-            } else {
-#pragma unroll
-                for (int mm = 0; mm < RG_TILE; ++mm) {
-                    const int col = c0 + mm;
-                    if (col >= 0 && col < w) out[col] = o[mm];
-                }
+                for (int j = 0; j < RG_VB; ++j) right[j] = b * RG_VB + j < h ? right[j] : 0.0f;
             }
+            float o[RG_VB];
+#pragma unroll
+            for (int j = 0; j < RG_VB; ++j) o[j] = rg_step<FMA>(st, left[j], right[j], n2, d1);
+            RG_V_LOAD(b + 3, (u + 3) % RG_PF)
+            emit(b, o);
         }
     }
-#undef RG_LOAD_TILE
+#undef RG_V_LOAD
 }
 
-// Vertical pass of the 15 horizontally blurred planes.  lane = column; grid = (ceil(w / 64), 15).
-template <bool FMA>
-__global__ __launch_bounds__(64) void k_rg_v(RgArgs a) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int w = a.w, h = a.h;
-    if (x >= w) return;
+// Vertical pass that writes its planes: the reference's mu1 / s11 (NK = 2: {x, x*x}, once per
+// search) -- and, in instrumented builds, the three per-pass planes for the parity tests (NK = 3).
+// One wave per plane and 64 columns; grid = sum over scales of 3 channels x ceil(w / 64).
+// Stores are unconditional too: rows outside the image go to a dump row.
+template <bool FMA, int NK>
+__global__ __launch_bounds__(64 * NK) void k_rg_v_emit(RgPlan p) {
+    int sc = 0, first = 0;
+#pragma unroll
+    for (int s = 0; s < kNumScales - 1; ++s)
+        if (s + 1 < p.nscales && (int)blockIdx.x >= p.vblk_end[s]) {
+            sc = s + 1;
+            first = p.vblk_end[s];
+        }
+    if (p.emit[sc] == nullptr) return;  // uniform (the instrumented builds' one-scale runs)
+    const int blk = (int)blockIdx.x - first;
+    const int ch = blk % 3, cg = blk / 3;
+    const int kind = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int w = p.w[sc], h = p.h[sc];
     const size_t n = (size_t)w * h;
-    const float* in = a.hout + blockIdx.y * n + x;
-    float* out = a.vout + blockIdx.y * n + x;
-    const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
-    const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
-    RgState st;
+    const int xc = min(cg * RG_VW + (int)(threadIdx.x & 63), w - 1);  // lanes right of the image shadow its last column
+    const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
+    float* out = p.emit[sc] + (size_t)(ch * NK + kind) * n;
+    float* dump = p.dump;
+    rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) st.p1[k] = st.p2[k] = 0.f;
-    // Ten rows per batch: the left-hand input in[m - 10] of a step is the right-hand one of the
-    // same slot of the previous batch, so every row is loaded once; the next batch's loads are in
-    // flight under this one's steps.
-    constexpr int U = 2 * RG_N;
-    float right[U], left[U], nright[U];
-#define RG_LOAD_ROWS(M0, R)                                          \
-    _Pragma("unroll") for (int j = 0; j < U; ++j) {                  \
-        const int m_ = (M0) + j; /* uniform */                       \
-        R[j] = m_ < h ? in[(size_t)m_ * w] : 0.f;                    \
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) right[j] = 0.f;  // rows -10 .. -1: the published zero padding
-    RG_LOAD_ROWS(0, nright)
-    for (int m0 = 0; m0 < h + RG_N - 1; m0 += U) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            left[j] = right[j];
-            right[j] = nright[j];
+        for (int j = 0; j < RG_VB; ++j) {
+            const int r = b * RG_VB + j - (RG_N - 1);  // output row (uniform)
+            float* row = r >= 0 && r < h ? out + (size_t)r * w : dump;
+            row[xc] = o[j];
         }
-        if (m0 + U < h + RG_N - 1) RG_LOAD_ROWS(m0 + U, nright)
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int m = m0 + j;
-            if (m < h + RG_N - 1) {
-                const float o = rg_step<FMA>(st, left[j], right[j], n2, d1);
-                if (m >= RG_N - 1) out[(size_t)(m - (RG_N - 1)) * w] = o;
-            }
-        }
-    }
-#undef RG_LOAD_ROWS
+    });
 }
 
-// Maps + partial sums.  grid = (RG_MAPS_BLOCKS, 3 channels), 256 threads; part[stat][block].
-__global__ __launch_bounds__(256) void k_rg_maps(RgArgs a, double* __restrict__ part) {
-    __shared__ double s_part[4][6];
-    const int ch = blockIdx.y, blk = blockIdx.x;
-    const size_t n = (size_t)a.w * a.h;
-    const size_t chunk = (n + RG_MAPS_BLOCKS - 1) / RG_MAPS_BLOCKS;
-    const size_t lo = (size_t)blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const float* v = a.vout + (size_t)ch * 5 * n;
-    const float* xa = a.xa + ch * n;
-    const float* xb = a.xb + ch * n;
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const float mu1 = v[i], mu2 = v[n + i], s11 = v[2 * n + i], s22 = v[3 * n + i], s12 = v[4 * n + i];
-        const float r1 = xa[i], r2 = xb[i];
-        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
-        const float dm = mu1 - mu2;
-        const float num_m = fmaf(-dm, dm, 1.0f);
-        const float num_s = fmaf(2.0f, s12 - mu12, kC2);
-        const float denom_s = ((s11 - mu11) + (s22 - mu22)) + kC2;
-        float d = 1.0f - div_rn(num_m * num_s, denom_s);
-        d = fmaxf(d, 0.0f);
-        const float ea = fabsf(r2 - mu2), eb = fabsf(r1 - mu1);
-        const float e = div_rn(ea - eb, 1.0f + eb);  // == (1+ea)/(1+eb) - 1, no cancellation
-        const float art = fmaxf(e, 0.0f), det = fmaxf(-e, 0.0f);
-        const float d2 = d * d, a2 = art * art, t2 = det * det;
-        acc[0] += (double)d;
-        acc[1] += (double)(d2 * d2);
-        acc[2] += (double)art;
-        acc[3] += (double)(a2 * a2);
-        acc[4] += (double)det;
-        acc[5] += (double)(t2 * t2);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// Vertical pass of a pass's planes + maps.  Waves 0-2 recurse {y, y*y, x*y} into a double-buffered
+// LDS tile of ten rows, waves 3-7 turn two of those rows each, with the cached mu1 / s11 and the two
+// frames' XYB values, into the six sums.  grid = sum over scales of 3 channels x ceil(w / 64).
+template <bool FMA>
+__global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
+    constexpr int NK = 3;
+    __shared__ float s_out[2][NK][RG_VB][RG_VW];
+    __shared__ double s_part[RG_MAPS_WAVES][6];
+    int sc = 0, first = 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane == 0) s_part[wave][k] = s;
+    for (int s = 0; s < kNumScales - 1; ++s)
+        if (s + 1 < p.nscales && (int)blockIdx.x >= p.vblk_end[s]) {
+            sc = s + 1;
+            first = p.vblk_end[s];
+        }
+    const int blk = (int)blockIdx.x - first;
+    const int ch = blk % 3, cg = blk / 3;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int w = p.w[sc], h = p.h[sc];
+    const size_t n = (size_t)w * h;
+    const int x = cg * RG_VW + lane;
+    const bool ok = x < w;
+    const int xc = min(x, w - 1);
+    const int nb = rg_v_batches(h);
+
+    if (wave < NK) {
+        const int kind = wave;
+        const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
+        rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
+#pragma unroll
+            for (int j = 0; j < RG_VB; ++j) s_out[b & 1][kind][j][lane] = o[j];
+            __syncthreads();  // batch b is in the tile
+        });
+    } else {
+        // maps: this wave's two rows of every batch; the same barriers as the recursion waves
+        const int j0 = 2 * (wave - NK);
+        const float* g_mu1 = p.cache[sc] + (size_t)(2 * ch) * n + xc;
+        const float* g_s11 = g_mu1 + n;
+        const float* g_r1 = p.xa[sc] + (size_t)ch * n + xc;
+        const float* g_r2 = p.xb[sc] + (size_t)ch * n + xc;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        float g[RG_PF][2][4];
+#define RG_M_LOAD(B, SLOT)                                                     \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                         \
+        const int r_ = (B) * RG_VB + j0 + jj - (RG_N - 1);                     \
+        const size_t o_ = (size_t)min(max(r_, 0), h - 1) * w;                  \
+        g[SLOT][jj][0] = g_mu1[o_];                                            \
+        g[SLOT][jj][1] = g_s11[o_];                                            \
+        g[SLOT][jj][2] = g_r1[o_];                                             \
+        g[SLOT][jj][3] = g_r2[o_];                                             \
+    }
+        RG_M_LOAD(0, 0)
+        RG_M_LOAD(1, 1)
+        RG_M_LOAD(2, 2)
+#pragma unroll 1
+        for (int b0 = 0; b0 < nb; b0 += RG_PF) {
+#pragma unroll
+            for (int u = 0; u < RG_PF; ++u) {
+                const int b = b0 + u;
+                RG_M_LOAD(b + 3, (u + 3) % RG_PF)
+                __syncthreads();  // batch b is in the tile
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int r = b * RG_VB + j0 + jj - (RG_N - 1);
+                    if (r >= 0 && r < h) {  // uniform
+                        const float mu2 = s_out[b & 1][0][j0 + jj][lane];
+                        const float s22 = s_out[b & 1][1][j0 + jj][lane];
+                        const float s12 = s_out[b & 1][2][j0 + jj][lane];
+                        double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                        rg_maps_pixel(g[u][jj][0], mu2, g[u][jj][1], s22, s12, g[u][jj][2], g[u][jj][3], z);
+                        if (ok) {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) acc[k] += z[k];
+                        }
+                    }
+                }
+            }
+        }
+#undef RG_M_LOAD
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double sum = wave_sum(acc[k]);
+            if (lane == 0) s_part[wave - NK][k] = sum;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 6) {
         const int k = threadIdx.x;
-        const double s = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
-        // stat index as k_finalize reads it: 0..5 ssim (c*2 + n), 6..17 edge (c*4 + j)
+        double sum = s_part[0][k];
+#pragma unroll
+        for (int m = 1; m < RG_MAPS_WAVES; ++m) sum += s_part[m][k];
+        // statistic index as k_finalize reads it: 0..5 ssim (c*2 + n), 6..17 edge (c*4 + j)
         const int stat = k < 2 ? ch * 2 + k : 6 + ch * 4 + (k - 2);
-        part[(size_t)stat * RG_MAPS_BLOCKS + blk] = s;
+        p.part[sc][(size_t)stat * p.vgroups[sc] + cg] = sum;
     }
 }
 
