@@ -151,14 +151,19 @@ typedef float rg_f4 __attribute__((ext_vector_type(4)));
 // 256 contiguous bytes (16 lanes per row: whole 64-byte segments per lane quad), one tile ahead of
 // its use; five ds_write_b128 put the tile into [row][column] order; each lane then reads its own
 // line 16 columns at a time (the three section lanes of a line read the same address: a
-// broadcast).  Outputs go back the same way: 16 columns per line into an LDS tile, five coalesced
-// 16-byte stores per 64 columns.  Wave-private LDS needs no barrier: the LDS executes one wave's
+// broadcast).  Outputs go back the same way: 16 columns per line into an LDS ring of 128 columns,
+// from which five coalesced 16-byte stores per lane write the 64-column segment that is ALIGNED
+// with the input tiles (a tile's own outputs are columns 64 T - 4 .. 64 T + 59; stored as they
+// fall they straddle the 64-byte lines: WRITE_SIZE showed 1.27x the plane bytes), one tile late.
+// Wave-private LDS needs no barrier: the LDS executes one wave's
 // instructions in order; __builtin_amdgcn_wave_barrier() only stops the COMPILER from moving an
 // access across it (it cannot see that lanes read what other lanes wrote).
 constexpr int RG_TW = 64;          // columns per staged tile
 constexpr int RG_TP = RG_TW + 4;   // LDS row pitch in floats (16-byte multiple; spreads the rows over the banks)
 constexpr int RG_TR = RG_HL / 4;   // 16-byte accesses per lane and tile (4 rows of 16 lanes each)
+constexpr int RG_OW = 2 * RG_TW;   // columns of the output ring
 typedef float RgTile[RG_HL][RG_TP];
+typedef float RgRing[RG_HL][RG_OW + 4];
 
 struct RgLine {
     const float* ga;        // plane(s) read (uniform)
@@ -190,8 +195,27 @@ __device__ __forceinline__ void rg_h_fetch(const RgLine& L, rg_f4 (&ra)[RG_TR], 
 // m - 10 and produces output column m - 4 (zeros outside the row: the published padding).
 // OPK: 0 = the plane itself, 1 = its square, 2 = the product of two planes (rounded to fp32 before
 // the blur, as published).  EDGE: the tile touches the row's first or last columns.
+// Segment S = output columns 64 S .. 64 S + 63 of the 20 rows, from the ring to the plane.
+template <bool EDGE>
+__device__ __forceinline__ void rg_h_store(const RgLine& L, const RgRing& tout, int S) {
+    const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < RG_TR; ++i) {
+        const rg_f4 v = *reinterpret_cast<const rg_f4*>(&tout[4 * i + rr][((S & 1) * RG_TW) + 4 * cc]);
+        float* dst = L.gout + ((size_t)L.goff[i] + (size_t)S * RG_TW);
+        if (!EDGE) {
+            __builtin_memcpy(dst, &v, 16);
+        } else {
+            const int col = S * RG_TW + 4 * cc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < L.w) dst[e] = v[e];
+        }
+    }
+}
+
 template <bool FMA, int OPK, bool EDGE>
-__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgTile& tout,
+__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout,
                                           rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
     const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
     __builtin_amdgcn_wave_barrier();
@@ -224,35 +248,23 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
             const float left = mm >= 2 * RG_N ? c[mm - 2 * RG_N] : pv[mm + RG_HT - 2 * RG_N];
             o[mm] = rg_step_lane<FMA>(L.p1, L.p2, left, c[mm], L.n2, L.d1);
         }
-        if (L.holds_out) {
+        if (L.holds_out) {  // output columns 64 T - 4 + 16 s ..: ring position = column mod 128
 #pragma unroll
             for (int v = 0; v < RG_HT / 4; ++v)
-                *reinterpret_cast<rg_f4*>(&tout[L.line][RG_HT * s + 4 * v]) =
+                *reinterpret_cast<rg_f4*>(&tout[L.line][(T * RG_TW - (RG_N - 1) + RG_HT * s + 4 * v) & (RG_OW - 1)]) =
                     rg_f4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
         }
     }
     __builtin_amdgcn_wave_barrier();
-    // tout = output columns 64 T - 4 .. 64 T + 59 of the 20 rows
-#pragma unroll
-    for (int i = 0; i < RG_TR; ++i) {
-        const rg_f4 v = *reinterpret_cast<const rg_f4*>(&tout[4 * i + rr][4 * cc]);
-        float* dst = L.gout + ((size_t)L.goff[i] + (size_t)T * RG_TW) - (RG_N - 1);
-        if (!EDGE) {
-            __builtin_memcpy(dst, &v, 16);
-        } else {
-            const int col = T * RG_TW - (RG_N - 1) + 4 * cc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e >= 0 && col + e < L.w) dst[e] = v[e];
-        }
-    }
+    if (T > 0) rg_h_store<EDGE>(L, tout, T - 1);  // uniform; segment T - 1 is complete now
 }
 
 template <bool FMA, int OPK>
-__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgTile& tout) {
+__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout) {
     const int w = L.w;
     const int ntiles = (w + (RG_N - 1) + RG_TW - 1) / RG_TW;  // steps run to m = w + 3
-    const int nmain = max(1, w / RG_TW);                      // tiles 1 .. nmain - 1 touch no edge
+    // tiles 1 .. nmain - 1 lie inside the row and complete a segment that does (64 (T + 1) <= w)
+    const int nmain = max(1, w / RG_TW);
     rg_f4 ra[RG_TR], rb[RG_TR];
 #pragma unroll
     for (int k = 0; k < RG_HT; ++k) L.cur[1][k] = 0.0f;  // columns -16 .. -1
@@ -264,6 +276,8 @@ __device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_
     for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin_a, tin_b, tout, ra, rb, T);
 #pragma unroll 1
     for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, ra, rb, T);
+    __builtin_amdgcn_wave_barrier();
+    rg_h_store<true>(L, tout, ntiles - 1);  // the row's last columns (w - 1 <= 64 (ntiles - 1) + 59)
 }
 
 // plane index among the 15 of a scale (5 * channel + {x, y, xx, yy, xy}) of plane `kind` of a pass
@@ -277,7 +291,7 @@ template <bool FMA, bool REF>
 __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {
     constexpr int NK = REF ? 2 : 3;
     __shared__ __attribute__((aligned(16))) RgTile s_in[REF ? 2 : 4];
-    __shared__ __attribute__((aligned(16))) RgTile s_o[NK];
+    __shared__ __attribute__((aligned(16))) RgRing s_o[NK];
     int sc = 0, first = 0;
 #pragma unroll
     for (int s = 0; s < kNumScales - 1; ++s)
