@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <future>
 #include <mutex>
@@ -130,7 +131,8 @@ thread_local std::string g_create_error;
 struct ssimu2_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
+    bool own_stream = false;   // created here, destroyed with the ctx
+    bool pool_stream = false;  // borrowed from the process-wide set of streams on distinct hardware queues
     std::string err;
 
     // capacity (bytes / floats / doubles currently allocated)
@@ -473,6 +475,17 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame
     *vblocks = vb_;
 }
 
+// Experiment knob of the instrumented build (always 0 in the product): dynamic LDS added to a
+// recursive-mode launch, which caps the workgroups a CU takes at once.
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+static int rg_extra_lds(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+#else
+static int rg_extra_lds(const char*) { return 0; }
+#endif
+
 // Instrumented builds (ssimu2_instr_rg_stop_after_scale): keep the raw planes of one scale for the
 // parity tests.  After a horizontal pass its planes are copied out of hbuf; the per-pass planes of
 // the vertical pass exist only in LDS, so k_rg_v_emit recomputes them into the debug buffer.
@@ -515,10 +528,11 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
     if (xblocks > 0) {  // a frame below 8 x 8 has no scale to score
         hipLaunchKernelGGL(k_rg_xyb, dim3(xblocks), dim3(256), 0, c->stream, rp);
-        if (fma) hipLaunchKernelGGL((k_rg_h<true, false>), dim3(hblocks), dim3(192), 0, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_h<false, false>), dim3(hblocks), dim3(192), 0, c->stream, rp);
-        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vblocks), dim3(512), 0, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vblocks), dim3(512), 0, c->stream, rp);
+        const int lds_h = rg_extra_lds("OAVIF_RG_LDS_H"), lds_v = rg_extra_lds("OAVIF_RG_LDS_V");
+        if (fma) hipLaunchKernelGGL((k_rg_h<true, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_h<false, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
+        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vblocks), dim3(512), lds_v, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vblocks), dim3(512), lds_v, c->stream, rp);
         if (dbg) {
             rg_debug_keep_h(c, p, rp, false);
             const int s = c->rg_dbg_scale;
@@ -625,6 +639,111 @@ const char* ssimu2_last_error(const ssimu2_ctx* ctx) {
 
 static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx);
 
+}  // extern "C"
+
+// ---- stream placement ---------------------------------------------------------------------------
+// HIP maps streams onto a few hardware queues, and two streams that share one do not overlap at
+// all: of six contexts created back to back on an MI355X the pairs (0,5), (1,4), (2,3) score at the
+// one-stream rate, every other pair 13 % faster (scripts/gpu_stream_pairs.py).  A caller that
+// scores independent frames on two contexts (a batch, speculative probes) cannot see this, so the
+// library places the streams: once per process and device it creates a few candidate streams,
+// runs short dependent spin kernels on pairs of them and keeps a set whose members all ran
+// CONCURRENTLY with each other.  Contexts created without a caller stream borrow the first free
+// member of that set (exclusively; ssimu2_ctx_destroy returns it), and only contexts beyond the
+// set get a stream of their own on whatever queue HIP picks.
+namespace {
+
+__global__ void k_spin(long long ticks) {  // one wave; wall_clock64 runs at 100 MHz
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+constexpr int kPoolCandidates = 6, kPoolMax = 4;
+struct StreamPool {
+    bool built = false;
+    int n = 0;
+    hipStream_t stream[kPoolMax] = {nullptr, nullptr, nullptr, nullptr};
+    bool in_use[kPoolMax] = {false, false, false, false};
+};
+std::mutex g_pool_mu;
+StreamPool g_pool[64];
+
+// Do streams a and b overlap their work?  Two dependent 100 us spin kernels on each, enqueued
+// alternately.  Kernels of ONE stream are ordered by barrier packets, and a barrier packet waits
+// for everything enqueued before it on its hardware queue -- the other stream's kernels too, if
+// the two streams share the queue: >= 300 us then, 200 us on distinct queues.  (One kernel per
+// stream proves nothing: without a barrier between them two packets of one queue run side by side.)
+bool streams_overlap(hipStream_t a, hipStream_t b) {
+    const long long ticks = 10000;  // 100 us
+    double best = 1e9;
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int k = 0; k < 2; ++k) {
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+        }
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        if (us < best) best = us;
+    }
+    return best < 260.0;
+}
+
+// caller holds g_pool_mu and has set the device
+void build_pool(StreamPool& pool) {
+    pool.built = true;
+    hipStream_t cand[kPoolCandidates];
+    int nc = 0;
+    for (; nc < kPoolCandidates; ++nc)
+        if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) != hipSuccess) break;
+    if (nc > 0) {  // code object load and clocks, untimed
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, cand[0], 2000LL);
+        (void)hipStreamSynchronize(cand[0]);
+    }
+    bool keep[kPoolCandidates] = {false};
+    for (int i = 0; i < nc && pool.n < kPoolMax; ++i) {
+        bool ok = true;
+        for (int j = 0; j < pool.n && ok; ++j) ok = streams_overlap(pool.stream[j], cand[i]);
+        if (ok) {
+            pool.stream[pool.n++] = cand[i];
+            keep[i] = true;
+        }
+    }
+    for (int i = 0; i < nc; ++i)
+        if (!keep[i]) (void)hipStreamDestroy(cand[i]);
+    (void)hipGetLastError();
+}
+
+hipStream_t pool_acquire(int device) {
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    StreamPool& pool = g_pool[device];
+    if (!pool.built) build_pool(pool);
+    for (int i = 0; i < pool.n; ++i)
+        if (!pool.in_use[i]) {
+            pool.in_use[i] = true;
+            return pool.stream[i];
+        }
+    return nullptr;
+}
+
+void pool_release(int device, hipStream_t s) {
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    StreamPool& pool = g_pool[device];
+    for (int i = 0; i < pool.n; ++i)
+        if (pool.stream[i] == s) pool.in_use[i] = false;
+}
+
+}  // namespace
+
+extern "C" {
+
 // ssimu2_prefetch: the once-per-process cost of the scorer (HIP runtime initialisation, loading
 // the code object, the constant table: 140-340 ms on the MI355X box, scripts/gpu_coldstart.py) on
 // a background thread, so that a one-image run hides it behind its image load and first encode.
@@ -695,6 +814,8 @@ static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     CREATE_TRY(hipSetDevice(device));
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
+    } else if ((c->stream = pool_acquire(device)) != nullptr) {
+        c->pool_stream = true;
     } else {
         CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
@@ -744,6 +865,7 @@ void ssimu2_ctx_destroy(ssimu2_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->pool_stream) pool_release(c->device, c->stream);
     delete c;
 }
 

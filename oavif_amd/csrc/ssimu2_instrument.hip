@@ -4,6 +4,7 @@
 // kernels, same host code, same flags) plus the entry points of include/ssimu2_hip_internal.h.
 // It is built into liboavif_hip_instr.so, which only bench.py, scripts/ and a few tests load;
 // liboavif_hip.so -- what a caller links -- contains none of this.
+#define SSIMU2_INSTRUMENTED_BUILD 1
 #include "ssimu2_hip.hip"
 
 #include "../../include/ssimu2_hip_internal.h"

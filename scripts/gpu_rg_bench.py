@@ -30,7 +30,7 @@ for k in range(1, NP):
 torch.cuda.synchronize()
 pr, pd = [a.data_ptr() for a, _ in pairs], [b.data_ptr() for _, b in pairs]
 
-s = oavif_amd.Ssimu2(0)
+s = oavif_amd.Ssimu2(0, instrumented=bool(os.environ.get('OAVIF_RG_INSTR')))
 fir = s.score_device(pr[0], pd[0], w, h)
 s.set_blur(mode)
 score = s.score_device(pr[0], pd[0], w, h)
