@@ -57,28 +57,9 @@ ALGO_BYTES_PER_PX_BLUR = 31.99
 
 
 def usable_cores() -> int:
-    """Host threads this process may really use: the cgroup CPU quota if there is one, else the
-    affinity mask, capped at 32 (the GPU box gives a 1-GPU job ~16 cores of a 256-thread host;
-    oversubscribing OpenMP 16x makes the CPU baseline 5x slower than it is)."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:
-        n = os.cpu_count() or 1
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, int(q / per + 0.5)))
-            break
-        except Exception:
-            continue
-    return max(1, min(n, 32))
+    """Host threads this process may really use (cgroup quota / affinity mask, capped at 32)."""
+    from oavif_amd import hostinfo
+    return hostinfo.usable_cores()
 
 
 def kernel_source_hash() -> str:

@@ -53,8 +53,13 @@ enum {
 #define SSIMU2_STATS_PER_SCALE 18
 
 /* Create a scorer bound to HIP device `device`.  If `hip_stream` is non-NULL it is a
-   hipStream_t owned by the caller that all work of this ctx is enqueued on; if NULL the
-   ctx creates (and later destroys) its own non-blocking stream. */
+   hipStream_t owned by the caller that all work of this ctx is enqueued on.  If NULL the library
+   provides a non-blocking stream, and places it: HIP maps streams onto a few hardware queues and
+   two streams on one queue do not overlap at all, so once per process and device the library
+   probes a few streams and keeps a set that run side by side; the first contexts created borrow
+   those (three with HIP's default of four hardware queues), so the scores of any two of them
+   overlap (13 % more throughput at 4K than two contexts that share a queue); further contexts
+   get a stream on whatever queue HIP picks. */
 int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx);
 
 /* Optional: start the once-per-process initialisation of `device` (HIP runtime, code object,
@@ -73,16 +78,25 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
 
 /* Which blur the scorer evaluates.  fssimu2's source is not available to this repository, so
    which of the two it follows is not known:
-     SSIMU2_BLUR_FIR        (default) the 9-tap impulse response of the published sigma-1.5
-                            recursive Gaussian, zero padding, fused kernels -- what bench.py measures;
-     SSIMU2_BLUR_RECURSIVE  the published recursion itself (libjxl FastGaussian: three second-order
-                            sections, products rounded to fp32 first, horizontal then vertical),
-                            operation for operation; about 9x slower at 4K (a recursion has no strips).
+     SSIMU2_BLUR_FIR        (default; the THROUGHPUT mode) the 9-tap impulse response of the
+                            published sigma-1.5 recursive Gaussian, zero padding, fused kernels --
+                            what bench.py measures: 0.16 ms per 4K pass;
+     SSIMU2_BLUR_RECURSIVE  (the CONSERVATIVE-PARITY mode) the published recursion itself (libjxl
+                            FastGaussian: three second-order sections, products rounded to fp32
+                            first, horizontal then vertical), operation for operation, planes
+                            bit-identical to the CPU checker's.  0.5 ms per 4K pass against a
+                            reference set with ssimu2_set_reference (whose XYB planes, blur(x) and
+                            blur(x*x) are then cached, so a pass recurses 9 of the 15 planes),
+                            0.9 ms for a pair score.
    The two differ by the recursion's own fp32 rounding noise, which grows with the line length:
    median 0.02 points on 384x256 frames, 0.13 at 1080p, 0.47 (max 2.4) at 4K; against the operator
    accumulated in fp64 the FIR form is within 0.0005 at 4K, the recursion about 1 point off.
-   Applies to every later score of the ctx; a cached reference is dropped.  Frames of more than
-   2^28 pixels are refused in recursive mode (144 bytes of planes per pixel). */
+   Applies to every later score of the ctx; a cached reference is dropped, and switching back to
+   SSIMU2_BLUR_FIR frees the recursive modes' planes.  Frames of more than 2^28 pixels are refused
+   in the recursive modes (by ssimu2_set_reference and by every scoring call, before anything is
+   enqueued).  Device memory of a ctx in these modes: 112 bytes per pixel (84 per pixel and scale:
+   0.40 GB of reference cache + 0.53 GB of per-pass planes at 4K), so the sixteen contexts of a
+   probe fan-out hold 15 GB at 4K. */
 enum { SSIMU2_BLUR_FIR = 0, SSIMU2_BLUR_RECURSIVE = 1,
        /* the same recursion with its last multiply-subtract fused, fma(-d1, prev, .), the way a
           compiler targeting an FMA unit contracts the published scalar code; the two orders are
@@ -149,7 +163,7 @@ int ssimu2_enqueue_against_reference_device(ssimu2_ctx* ctx, const void* d_dist)
 int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_STATS_PER_SCALE],
                          int* out_num_scales);
 
-/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v4 (...)". */
+/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v6 (...)". */
 const char* ssimu2_version(void);
 
 #if defined(__GNUC__)

@@ -1,11 +1,14 @@
 """Batch driver: the MI355X-side counterpart of /root/reference/scripts/measure.py.
 
 measure.py runs the `oavif` binary once per image, one after another (measure.py:151-158).
-Here every rank of a `torch.distributed` job (one process per GPU) takes the images
-`rank, rank + world, ...` of the same sorted list (measure.py:137-140), runs the target-quality
-search for each (CPU libavif/aom encode + dav1d decode through Pillow, scorer on this rank's
-GPU), and the per-image result records are gathered to every rank with ONE all_gather
-(RCCL when the backend is nccl).  There is no data-path collective: images are independent.
+Here every rank of a `torch.distributed` job (one process per GPU) takes its share of the same
+sorted list (measure.py:137-140) -- dealt largest file first to the least loaded rank, so the
+ranks' byte loads are even ("sort/largest-first if sizes vary") -- runs the
+target-quality search for each (CPU libavif/aom encode + dav1d decode through Pillow, scorer on
+this rank's GPU) on host cores near that GPU (the rank pins itself to its slice of the node's
+cores before its first GPU call, oavif_amd.hostinfo), and the per-image result records are
+gathered to every rank with ONE all_gather (RCCL when the backend is nccl).  There is no
+data-path collective: images are independent.
 
 Kept from the reference: image selection (.png/.jpg/.jpeg, sorted), CSV header, column order
 and number formats (measure.py:178-206), the summary statistics (measure.py:209-269), the
@@ -74,8 +77,24 @@ def list_images(images_dir) -> List[Path]:
 
 
 def shard(n_items: int, rank: int, world: int) -> List[int]:
-    """Image i goes to rank i mod world."""
+    """Image i goes to rank i mod world (equal-sized inputs)."""
     return list(range(rank, n_items, world))
+
+
+def deal_largest_first(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time dealing: images in order of decreasing size (ties: lower index
+    first), each to the rank with the smallest byte load so far (ties: lower rank).  Returns the
+    index list of every rank, each in dealing order (largest first, so a rank's worker threads
+    start its long encodes first and the tail is short).  Deterministic: every rank computes the
+    same table from the same directory listing.  With equal sizes this is i mod world."""
+    world = max(1, int(world))
+    loads = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(sizes)), key=lambda k: (-int(sizes[k]), k)):
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += int(sizes[i])
+    return out
 
 
 # ---- one image ---------------------------------------------------------------------------------
@@ -112,11 +131,22 @@ def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float 
 
 def output_names(image_files: Sequence[Path]) -> List[str]:
     """One .avif name per input: `<stem>.avif` as measure.py writes it (measure.py:49), or
-    `<stem>_<ext>.avif` for inputs whose stem is shared (a.png + a.jpg), so that concurrent
-    workers / ranks never write the same file."""
+    `<stem>_<ext>.avif` for inputs whose stem is shared (a.png + a.jpg); a name that is still
+    taken (a.png + a.jpg + a_png.webp-style stems, a.JPG + a.jpg) gets the input's position in
+    the list appended.  The names are unique among themselves, so concurrent workers / ranks
+    never write or unlink the same file."""
     stems = [p.stem for p in image_files]
-    return [f"{p.stem}.avif" if stems.count(p.stem) == 1 else f"{p.stem}_{p.suffix.lstrip('.').lower()}.avif"
-            for p in image_files]
+    names = [f"{p.stem}.avif" if stems.count(p.stem) == 1 else f"{p.stem}_{p.suffix.lstrip('.').lower()}.avif"
+             for p in image_files]
+    taken = set()
+    for i, name in enumerate(names):
+        if name in taken or names.count(name) > 1:
+            name = f"{name[:-5]}_{i}.avif"
+            while name in taken:
+                name = f"{name[:-5]}_.avif"
+            names[i] = name
+        taken.add(name)
+    return names
 
 
 # ---- gather ----------------------------------------------------------------------------------------
@@ -131,15 +161,17 @@ def pack_records(results: Sequence[ImageResult]) -> np.ndarray:
     return rec
 
 
-def gather_records(local: np.ndarray, n_total: int, device=None) -> np.ndarray:
+def gather_records(local: np.ndarray, n_total: int, device=None, per_rank: Optional[int] = None) -> np.ndarray:
     """All-gather the (n_local, 8) float64 record arrays of all ranks -> (n_total, 8) sorted by
-    image index.  One collective; works on gloo (CPU tensors) and nccl = RCCL (GPU tensors)."""
+    image index.  One collective; works on gloo (CPU tensors) and nccl = RCCL (GPU tensors).
+    `per_rank`: rows of the fixed-size buffer every rank contributes (the largest shard)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local[np.argsort(local[:, 0])] if len(local) else local
     world = dist.get_world_size()
-    per_rank = (n_total + world - 1) // world
+    if per_rank is None:
+        per_rank = (n_total + world - 1) // world
     buf = torch.full((per_rank, RECORD_FIELDS), -2.0, dtype=torch.float64)
     if len(local):
         buf[: len(local)] = torch.from_numpy(local)
@@ -236,9 +268,11 @@ def summarize(results: Sequence[ImageResult], wall_s: float, world: int = 1) -> 
 # ---- driver ----------------------------------------------------------------------------------------
 
 def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tuple], rank: int = 0,
-              world: int = 1, gather_device=None, log=None, workers: int = 1) -> List[ImageResult]:
+              world: int = 1, gather_device=None, log=None, workers: int = 1,
+              deal: Optional[List[List[int]]] = None) -> List[ImageResult]:
     """Process this rank's shard with `encode_fn(index, path) -> (q, score, passes, final_bytes)`
-    and return the gathered, index-sorted results of ALL ranks.
+    and return the gathered, index-sorted results of ALL ranks.  `deal`: the index list of every
+    rank (default: deal_largest_first over the files' sizes).
 
     `workers` > 1 runs that many images of the shard concurrently in threads: the CPU codec
     (libavif/aom through Pillow releases the GIL) is 3-4 orders of magnitude slower than the GPU
@@ -266,14 +300,17 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
                 log(res.error)
         return res
 
-    mine = shard(len(image_files), rank, world)
+    if deal is None:
+        deal = deal_largest_first([_size_or_zero(p) for p in image_files], world)
+    mine = deal[rank]
     if workers > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=workers) as ex:
             local = list(ex.map(one, mine))
     else:
         local = [one(i) for i in mine]
-    rec = gather_records(pack_records(local), len(image_files), gather_device)
+    rec = gather_records(pack_records(local), len(image_files), gather_device,
+                         per_rank=max(len(d) for d in deal))
     names = [p.name for p in image_files]
     results = records_to_results(rec, names)
     for r in results:  # error strings stay on the rank that produced them; keep local ones
@@ -282,6 +319,22 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
         elif r.status == "error":
             r.error = "error on another rank (see its log)"
     return results
+
+
+def _size_or_zero(p: Path) -> int:
+    try:
+        return p.stat().st_size
+    except OSError:
+        return 0
+
+
+def default_workers() -> int:
+    """Images encoded concurrently per rank: this rank's share of the host cores the job may use
+    (cgroup quota / affinity mask, not os.cpu_count(): the GPU host has 256 threads, a job's
+    cgroup 16 per GPU), one encoder thread per image as oavif defaults (parse_args.zig:51)."""
+    from . import hostinfo
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    return max(1, min(16, hostinfo.usable_cores(cap=16 * local_world) // local_world))
 
 
 def parse_cli(argv=None):
@@ -296,8 +349,11 @@ def parse_cli(argv=None):
     ap.add_argument("--max-pass", type=int, default=6)        # parse_args.zig:59
     ap.add_argument("--speed", type=int, default=9)           # parse_args.zig:50
     ap.add_argument("--keep", action="store_true", help="keep the generated .avif files")
-    ap.add_argument("--workers", type=int, default=max(1, min(16, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))),
-                    help="images encoded concurrently per rank (threads; one scorer context each)")
+    ap.add_argument("--workers", type=int, default=default_workers(),
+                    help="images encoded concurrently per rank (threads; one scorer context each); "
+                         "default: the rank's share of the usable host cores")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not pin the rank to its slice of the node's host cores")
     ap.add_argument("--out-dir", default="temp_avif_output")
     args = ap.parse_args(argv)
     if len(args.paths) == 2:
@@ -314,12 +370,20 @@ def parse_cli(argv=None):
 
 def main(argv=None) -> int:
     args = parse_cli(argv)
-
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    # Host placement first -- before torch is imported, before any GPU call, before a thread
+    # exists: every thread started later (encoder workers, the HIP runtime's) inherits the mask.
+    from . import hostinfo
+    core_sets = hostinfo.rank_core_sets(local_world, gpu_cpulists=hostinfo.gpu_local_cpulists() or None,
+                                        quota=hostinfo.cgroup_cpu_quota())
+    if not args.no_pin and world > 1:
+        hostinfo.pin_rank(local_rank, local_world)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         print("oavif_amd.batch: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
         return 3
@@ -370,7 +434,7 @@ def main(argv=None) -> int:
                         log=lambda s: print(s, file=sys.stderr), workers=args.workers)
     wall = time.perf_counter() - t0
     if not args.keep:
-        for i in shard(len(files), rank, world):
+        for i in deal_largest_first([_size_or_zero(p) for p in files], world)[rank]:
             try:
                 (out_dir / names[i]).unlink()
             except OSError:
@@ -378,6 +442,12 @@ def main(argv=None) -> int:
     if rank == 0:
         write_csv(args.output_csv, results)
         print(summarize(results, wall, world))
+        pinned = "" if (not args.no_pin and world > 1) else " (not pinned)"
+        print(f"Host cores per rank{pinned}: " + "; ".join(
+            f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
+        print(f"Worker threads per rank: {args.workers}; dealing: largest file first")
+        print("Note: the stand-in codec (Pillow's libavif) writes 8-bit AVIF where oavif defaults to 10-bit "
+              "(parse_args.zig:56): byte sizes and chosen quantizers are not those of the reference's measure.py run")
         print(f"\nResults written to {args.output_csv}")
     for sc in all_scorers:
         sc.close()

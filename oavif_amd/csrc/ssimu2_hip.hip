@@ -616,7 +616,7 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v5 (pair ring, b64 taps, dword pixel loads; optional recursive blur)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v6 (pair ring, b64 taps, dword pixel loads; recursive blur: cached reference, 3 lanes per line; placed streams)"; }
 
 int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;

@@ -1,0 +1,157 @@
+"""Host-side placement for one-process-per-GPU jobs ("CPU encode/decode for that image
+runs on host cores near that GPU").
+
+The CPU codec is 3-4 orders of magnitude slower than the GPU score, so where a rank's encoder
+threads run IS the multi-GPU result of a batch.  Everything here is plain Linux (affinity mask,
+cgroup quota, sysfs); nothing touches the GPU, so a rank can pin itself before its first HIP call.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Dict, List, Optional, Sequence
+
+
+def allowed_cpus() -> List[int]:
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except Exception:
+        return list(range(os.cpu_count() or 1))
+
+
+def cgroup_cpu_quota() -> Optional[float]:
+    """CPUs' worth of time the cgroup grants this process (cpu.max / cfs quota), None = no limit."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return int(txt[0]) / int(txt[1])
+            q = int(txt[0])
+            if q <= 0:
+                return None
+            return q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            continue
+    return None
+
+
+def usable_cores(cap: int = 32) -> int:
+    """Host threads this process may really use: the cgroup CPU quota if there is one, else the
+    affinity mask, capped (the GPU box gives a 1-GPU job ~16 cores of a 256-thread host;
+    oversubscribing OpenMP 16x makes a CPU baseline 5x slower than it is)."""
+    n = len(allowed_cpus())
+    q = cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.5)))
+    return max(1, min(n, cap))
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """"0-3,8,10-11" -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs cpulist files)."""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_local_cpulists(sysfs: str = "/sys") -> List[List[int]]:
+    """local_cpulist (the cores of the NUMA node a device hangs off) of every AMD display-class PCI
+    function, in PCI address order -- the order the ROCm runtime enumerates devices in when no
+    *_VISIBLE_DEVICES remapping is active.  [] when sysfs does not say."""
+    found = []
+    for dev in sorted(glob.glob(os.path.join(sysfs, "bus/pci/devices/*"))):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            if not open(os.path.join(dev, "class")).read().strip().startswith(("0x03", "0x12")):
+                continue  # display controllers and processing accelerators only
+            cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        except Exception:
+            continue
+        if cpus:
+            found.append(cpus)
+    return found
+
+
+def sibling_order(cpus: Sequence[int], sysfs: str = "/sys") -> List[int]:
+    """`cpus` ordered so that the hardware threads of one physical core are neighbours (key: the
+    lowest thread id of the core, from topology/thread_siblings_list): a contiguous slice then
+    holds whole cores instead of sharing each core with the slice 128 ids further on."""
+    def key(c: int):
+        try:
+            sib = parse_cpulist(open(os.path.join(sysfs, f"devices/system/cpu/cpu{c}/topology/thread_siblings_list")).read())
+            return (min(sib), c)
+        except Exception:
+            return (c, c)
+    return sorted(cpus, key=key)
+
+
+def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
+                   gpu_cpulists: Optional[Sequence[Sequence[int]]] = None,
+                   quota: Optional[float] = None) -> List[List[int]]:
+    """Disjoint host core sets for the `local_world` ranks of one node, rank r <-> GPU r.
+
+    Ranks whose GPUs share a NUMA node split that node's allowed cores into contiguous slices
+    (in the order given: sibling_order keeps the hardware threads of a core together);
+    without usable sysfs topology the whole allowed set is split the same way.  With a cgroup
+    quota below the allowed core count every slice is cut to its share of the quota, so the ranks
+    together never run more threads than the cgroup will schedule.  Deterministic: every rank
+    computes the same table."""
+    cpus = list(cpus) if cpus is not None else sibling_order(allowed_cpus())
+    local_world = max(1, int(local_world))
+    groups: Dict[tuple, List[int]] = {}
+    if gpu_cpulists is not None and len(gpu_cpulists) >= local_world:
+        allowed = set(cpus)
+        for r in range(local_world):
+            nearset = set(gpu_cpulists[r])
+            near = tuple(c for c in cpus if c in nearset and c in allowed)
+            if not near:
+                groups = {}
+                break
+            groups.setdefault(near, []).append(r)
+    if not groups:
+        groups = {tuple(cpus): list(range(local_world))}
+    sets: List[List[int]] = [[] for _ in range(local_world)]
+    for near, ranks in groups.items():
+        m = len(ranks)
+        per = max(1, len(near) // m)
+        for k, r in enumerate(ranks):
+            lo = min(k * per, max(len(near) - 1, 0))
+            sets[r] = list(near[lo: lo + per]) or [near[-1]]
+    if quota is not None:
+        share = max(1, int(quota / local_world + 0.5))
+        sets = [s[:share] for s in sets]
+    return sets
+
+
+def pin_rank(local_rank: int, local_world: int) -> List[int]:
+    """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
+    before the first GPU call and before any thread pool exists.  Returns the set."""
+    sets = rank_core_sets(local_world, gpu_cpulists=gpu_local_cpulists() or None, quota=cgroup_cpu_quota())
+    mine = sets[local_rank % len(sets)]
+    try:
+        os.sched_setaffinity(0, mine)
+    except Exception:
+        pass  # not fatal: the rank then runs wherever the launcher put it
+    return mine
+
+
+def format_cpus(cpus: Sequence[int]) -> str:
+    """[0, 1, 2, 3, 8] -> "0-3,8"."""
+    cpus = sorted(cpus)
+    parts, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(parts)

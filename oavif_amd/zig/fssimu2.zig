@@ -45,18 +45,24 @@ pub var device: c_int = 0;
 
 /// oavif scores every pass of a search against the same `e.rgb` slice (main.zig:86,
 /// tq.zig:37).  When true, a reference slice with the same pointer, length, dimensions and
-/// content fingerprint (64 sampled bytes) as the previous call is uploaded (and its caches
-/// built) only once.  Set to false -- or call invalidateReference() -- if the caller rewrites
+/// content fingerprint (4 KiB of it: 64 runs of 64 bytes spread over the frame) as the previous
+/// call is uploaded (and its caches built) only once.  Set to false -- or call invalidateReference() -- if the caller rewrites
 /// the reference buffer in place between calls; hosts that process several images per process
 /// should call invalidateReference() when an image's `e.rgb` is freed (INTEGRATION.md 2a).
 pub var cache_reference: bool = true;
 
-/// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur): `.fir`, the fused
-/// 9-tap kernels (default, what the benchmarks measure), or `.recursive`, the published recursive
-/// Gaussian operation for operation (about 9x slower at 4K, 1.4 ms per score).  The two
-/// differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5 at 4K); which of
-/// them fssimu2 0.1.1 agrees with could not be checked where this shim was written.  Set before
-/// the first call.
+/// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur):
+///   `.fir`        the THROUGHPUT mode (default; what the benchmarks measure): the fused 9-tap
+///                 kernels, 0.16 ms per 4K pass;
+///   `.recursive`  the CONSERVATIVE-PARITY mode: the published recursive Gaussian operation for
+///                 operation (libjxl's order; planes bit-identical to the CPU checker's), 0.5 ms per
+///                 4K pass with the reference cached -- still 0.3 % of a pass's encode + decode.
+/// The two differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5
+/// at 4K, where a third of the searches then end on another quantizer); which of them fssimu2
+/// 0.1.1 agrees with could not be checked where this shim was written.  A maintainer who can run
+/// fssimu2 should score a few 4K pairs in both modes once and set the one that matches; if in
+/// doubt for a search (where the encode dominates anyway) `.recursive` follows the published
+/// arithmetic.  Set before the first call.
 pub const Blur = enum(c_int) { fir = 0, recursive = 1, recursive_fma = 2 };
 pub var blur: Blur = .fir;
 
@@ -95,18 +101,26 @@ fn context() Error!*Ctx {
     return c.?;
 }
 
-/// A cheap content fingerprint of the reference: FNV-1a over 64 bytes sampled at 64 evenly spaced
-/// positions.  The cached reference is keyed on (pointer, length, size, fingerprint): an allocator
-/// that hands a freed `e.rgb` address to the next same-sized image no longer makes the shim score
-/// against the previous image's cached pyramid (oavif today handles one image per process, so
-/// this cannot happen yet; a multi-image host should still call invalidateReference()).
+/// A cheap content fingerprint of the reference: FNV-1a over 4 KiB of it -- 64 runs of 64
+/// consecutive bytes at evenly spaced positions (flat borders or letterbox bars defeat single
+/// sampled bytes; a run that crosses 21 pixels mostly does not).  The cached reference is keyed on
+/// (pointer, length, size, fingerprint): an allocator that hands a freed `e.rgb` address to the
+/// next same-sized image no longer makes the shim score against the previous image's cached
+/// planes (oavif today handles one image per process, so this cannot happen yet; a multi-image
+/// host should still call invalidateReference()).
 fn fingerprint(buf: []const u8) u64 {
     var h: u64 = 0xcbf29ce484222325;
     if (buf.len == 0) return h;
-    const step: usize = @max(buf.len / 64, 1);
-    var i: usize = 0;
-    while (i < buf.len) : (i += step) {
-        h = (h ^ buf[i]) *% 0x100000001b3;
+    const runs: usize = 64;
+    const run_len: usize = @min(64, buf.len);
+    const step: usize = @max((buf.len - run_len) / runs, 1);
+    var start: usize = 0;
+    var k: usize = 0;
+    while (k < runs and start + run_len <= buf.len) : (k += 1) {
+        for (buf[start .. start + run_len]) |b| {
+            h = (h ^ b) *% 0x100000001b3;
+        }
+        start += step;
     }
     return h;
 }
@@ -179,9 +193,19 @@ pub fn computeSsimu2(
             try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
             rememberReference(reference, width, height);
         }
-        try check(ssimu2_score_against_reference(ctx, distorted.ptr, &score));
+        const rc = ssimu2_score_against_reference(ctx, distorted.ptr, &score);
+        if (rc == -5) { // the context lost its reference (e.g. a pair score in between): upload once more
+            try check(ssimu2_set_reference(ctx, reference.ptr, width, height));
+            rememberReference(reference, width, height);
+            try check(ssimu2_score_against_reference(ctx, distorted.ptr, &score));
+            return score;
+        }
+        try check(rc);
         return score;
     }
+    // ssimu2_score_rgb8 overwrites the context's reference planes: the shim's record of a cached
+    // reference must not outlive them
+    g_ref_ptr = null;
     try check(ssimu2_score_rgb8(ctx, reference.ptr, distorted.ptr, width, height, channels, &score));
     return score;
 }

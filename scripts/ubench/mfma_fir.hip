@@ -60,6 +60,57 @@ __global__ void k_rate(float* out, int iters, float w, float x) {
     if (s == 12345.678f) out[0] = s;
 }
 
+// The arrangement MI355X_MICROARCH.md describes for the two pipes ("a MFMA-only wave and a
+// VALU-only wave on the same CU run concurrently"): blocks alternate between the MFMA loop and the
+// v_fmac loop, so every SIMD holds wps / 2 waves of each kind.  If the pipes co-execute ACROSS
+// waves the launch takes about max(MFMA waves alone, VALU waves alone); if they share issue, the sum.
+__global__ void k_split(float* out, int iters, float w, float x) {
+    f4 acc[3];
+    float v[12];
+    for (int i = 0; i < 3; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 12; ++i) v[i] = threadIdx.x + i;
+    const float sw = __builtin_amdgcn_readfirstlane(__float_as_int(w)) ? w : x;
+    float a = w + (threadIdx.x & 3), b = x + threadIdx.x;
+    if (blockIdx.x & 1) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[g], 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 9; ++j) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[j]) : "s"(sw), "v"(b));
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 3; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 12; ++i) s += v[i];
+    if (s == 12345.678f) out[0] = s;
+}
+
+static void rate_split(float* d) {
+    const int iters = 20000;
+    for (int wps = 2; wps <= 8; wps += 2) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        hipLaunchKernelGGL(k_split, dim3(256 * wps), dim3(256), 0, 0, d, 4000, 0.999f, 0.001f);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_split, dim3(256 * wps), dim3(256), 0, 0, d, iters, 0.999f, 0.001f);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("split: %d mfma-only + %d v_fmac-only waves per SIMD  %.3f ms -> %.2f ns per round of iterations "
+               "(every wave one iteration: %d x 12 mfma + %d x 36 v_fmac per SIMD)\n",
+               wps / 2, wps / 2, ms, ms * 1e6 / iters, wps / 2, wps / 2);
+    }
+}
+
 template <int MODE>
 static void rate(float* d) {
     const int iters = 20000;
@@ -123,5 +174,6 @@ int main() {
     rate<M_VALU>(dz);
     rate<M_BOTH>(dz);
     rate<M_BOTH2>(dz);
+    rate_split(dz);
     return 0;
 }

@@ -29,10 +29,16 @@ def main():
     from oavif_amd import batch
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
-    if world > 1:
+    from oavif_amd import hostinfo
+    if world > 1:   # what batch.main does before its first GPU call
+        hostinfo.pin_rank(rank, world)
         dist.init_process_group(backend="gloo")
     files = batch.list_images(images_dir)
     results = batch.run_batch(files, scripted_encode, rank, world, workers=int(os.environ.get('BATCH_WORKERS', '1')))
+    deal = batch.deal_largest_first([p.stat().st_size for p in files], world)
+    json.dump({"rank": rank, "affinity": sorted(os.sched_getaffinity(0)), "indices": deal[rank],
+               "bytes": sum(files[i].stat().st_size for i in deal[rank])},
+              open(f"{out_json}.rank{rank}", "w"))
     if rank == 0:
         batch.write_csv(out_json + ".csv", results)
         json.dump([[r.index, r.image, r.status, r.q, r.score, r.passes, r.orig_bytes, r.final_bytes]

@@ -1,5 +1,6 @@
 """Multi-rank path on CPU: world_size 2 over gloo must produce the same gathered records as a
-single process (images shard i mod N, one all_gather of fixed-size records)."""
+single process (images dealt largest-first over the ranks, one all_gather of fixed-size records,
+ranks pinned to disjoint host core sets: SURVEY.md 8e)."""
 import csv
 import json
 import os
@@ -54,6 +55,71 @@ def test_shard_rule():
     assert batch.shard(10, 3, 4) == [3, 7]
     assert sorted(sum((batch.shard(257, r, 8) for r in range(8)), [])) == list(range(257))
     assert batch.shard(3, 5, 8) == []
+
+
+def test_largest_first_dealing():
+    """"sort/largest-first if sizes vary".  Deterministic, a partition, i mod N for
+    equal sizes, and byte loads within 10 % of each other on a spread of sizes."""
+    from oavif_amd import batch
+    assert batch.deal_largest_first([7] * 10, 4) == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    rng = np.random.default_rng(3)
+    sizes = [int(x) for x in rng.integers(200_000, 9_000_000, 256)]
+    deal = batch.deal_largest_first(sizes, 8)
+    assert sorted(sum(deal, [])) == list(range(256)) and deal == batch.deal_largest_first(sizes, 8)
+    loads = [sum(sizes[i] for i in d) for d in deal]
+    assert max(loads) <= 1.10 * min(loads), loads
+    assert all(sizes[a] >= sizes[b] for d in deal for a, b in zip(d, d[1:]))   # each rank: largest first
+    mod = [sum(sizes[i] for i in range(r, 256, 8)) for r in range(8)]
+    assert max(loads) - min(loads) < max(mod) - min(mod)                        # better than i mod N
+    assert batch.deal_largest_first([5, 1], 4) == [[0], [1], [], []]
+
+
+def test_rank_core_sets_are_disjoint_near_their_gpu_and_within_the_quota():
+    from oavif_amd import hostinfo
+    sets = hostinfo.rank_core_sets(8, cpus=list(range(256)))
+    assert [len(s) for s in sets] == [32] * 8 and len(set(sum(sets, []))) == 256
+    # two sockets, four GPUs each; cores 0-63 + their SMT siblings 128-191 on socket 0
+    s0 = list(range(0, 64)) + list(range(128, 192))
+    s1 = list(range(64, 128)) + list(range(192, 256))
+    sets = hostinfo.rank_core_sets(8, cpus=list(range(256)), gpu_cpulists=[s0] * 4 + [s1] * 4)
+    assert all(set(sets[r]) <= set(s0) for r in range(4)) and all(set(sets[r]) <= set(s1) for r in range(4, 8))
+    assert len(set(sum(sets, []))) == sum(len(s) for s in sets) == 256
+    # a cgroup that grants 16 CPUs to a job of two ranks: eight threads each, still disjoint
+    sets = hostinfo.rank_core_sets(2, cpus=list(range(256)), quota=16.0)
+    assert [len(s) for s in sets] == [8, 8] and not set(sets[0]) & set(sets[1])
+    assert hostinfo.rank_core_sets(3, cpus=[4, 5]) == [[4], [5], [5]]      # more ranks than cores: still a set each
+    assert hostinfo.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert hostinfo.format_cpus([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    assert 1 <= hostinfo.usable_cores() <= 32
+
+
+@pytest.fixture(scope="module")
+def varied_dir(tmp_path_factory, hip_lib):
+    from PIL import Image
+    d = tmp_path_factory.mktemp("varied")
+    rng = np.random.default_rng(5)
+    for k in range(20):
+        side = int(rng.integers(16, 160))
+        img = Image.fromarray(rng.integers(0, 256, (side, side + 8, 3), dtype=np.uint8))
+        img.save(d / f"v{k:02d}.png")
+    return d
+
+
+def test_world2_placement_csv_equal_loads_even_affinity_disjoint(varied_dir, tmp_path):
+    """two ranks over files of very different sizes -- the gathered CSV equals
+    the one-rank run's, the ranks' byte loads are within 10 %, and the ranks pinned themselves to
+    disjoint core sets."""
+    single, _ = _run(1, varied_dir, tmp_path / "v1.json")
+    double, _ = _run(2, varied_dir, tmp_path / "v2.json")
+    assert single == double and len(single) == 20
+    def rows(path):   # every column but the wall-clock one
+        return [r[:5] + r[6:] for r in csv.reader(open(path))]
+    assert rows(str(tmp_path / "v1.json") + ".csv") == rows(str(tmp_path / "v2.json") + ".csv")
+    r = [json.load(open(f"{tmp_path / 'v2.json'}.rank{k}")) for k in range(2)]
+    assert sorted(r[0]["indices"] + r[1]["indices"]) == list(range(20))
+    assert max(r[0]["bytes"], r[1]["bytes"]) <= 1.10 * min(r[0]["bytes"], r[1]["bytes"]), (r[0]["bytes"], r[1]["bytes"])
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert r[0]["affinity"] and r[1]["affinity"] and not set(r[0]["affinity"]) & set(r[1]["affinity"])
 
 
 def test_world2_gloo_matches_single_process(image_dir, tmp_path):
@@ -111,6 +177,10 @@ def test_output_names_never_collide(tmp_path):
     names = batch.output_names(files)
     assert names == ["a_png.avif", "a_jpg.avif", "b.avif", "c.avif"]
     assert len(set(names)) == len(names)
+    # names that collide after the first rule (a_png.webp-style stems, a.JPG + a.jpg)
+    files = [tmp_path / n for n in ("a.png", "a.jpg", "a_png.jpeg", "b.JPG", "b.jpg", "c.png")]
+    names = batch.output_names(files)
+    assert len(set(names)) == len(names) == 6 and names[5] == "c.avif" and names[1] == "a_jpg.avif"
 
 
 def test_batch_and_cli_share_one_encode_path_and_keep_alpha(tmp_path, monkeypatch):
