@@ -347,15 +347,17 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         # The reference encodes 10-bit when --tenbit 1 or the source is 16-bit (io.zig:546-548).
         # Pillow's libavif plugin, the stand-in codec here, writes 8-bit only: say what is written.
         out_depth = 8
-        if o.tenbit or hbd:
-            eprint("note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); "
-                   "the stand-in codec (Pillow's libavif) writes 8-bit, so sizes and the chosen q are not "
-                   "comparable with oavif's own output")
+        # ... after the reference's own lines, so their order (main.zig:78-116, what tools parse) is kept
+        depth_note = ("note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); "
+                      "the stand-in codec (Pillow's libavif) writes 8-bit, so sizes and the chosen q are not "
+                      "comparable with oavif's own output") if (o.tenbit or hbd) else None
         if o.quality is not None:  # bypass the search (main.zig:93-100)
             eprint(f"Encoding [q{o.quality}, speed {o.speed}, {out_depth}-bit]")
             data = _encode(src, o, o.quality)
             open(out, "wb").write(data)
             eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
+            if depth_note:
+                eprint(depth_note)
             return 0
 
         eprint(f"Searching [tgt {_fmt_num(o.score_tgt)}±{o.tolerance:.1f}, speed {o.speed}, {out_depth}-bit]")
@@ -402,6 +404,8 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
             data = _encode(src, o, r.q)
         open(out, "wb").write(data)
         eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
+        if depth_note:
+            eprint(depth_note)
         return 0
     except CliError as e:
         eprint(f"error: {e.name}")
