@@ -323,7 +323,7 @@ PyrBandArgs pyramid_args(const Pyramid& p, int nframes, const uint8_t* const* fr
     a.bands_y = (p.h[0] + PYR_BAND_H - 1) / PYR_BAND_H;
     for (int f = 0; f < nframes; ++f) {
         a.in[f] = frames[f];
-        for (int l = 0; l < a.nlevels; ++l) a.out[f][l] = lin[f] + p.lin_off[l + 1];
+        for (int l = 0; l < a.nlevels; ++l) a.out[f][l] = lin[f] ? lin[f] + p.lin_off[l + 1] : nullptr;
     }
     return a;
 }
@@ -435,10 +435,9 @@ int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
     return SSIMU2_OK;
 }
 
-// Plan of one frame's share of a recursive-mode score: `ref_frame` selects the reference's
-// buffers (XYB out = xa, linear pyramid = d_lin_ref) or the distorted frame's.
-void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, bool ref_frame, RgPlan* rp,
-                   int* xblocks, int* hblocks, int* vblocks) {
+// Plan of one frame's share of a recursive-mode score: `ref_frame` selects where the frame's XYB
+// planes go (xa, the reference's, or xb).
+void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, bool ref_frame, RgPlan* rp, int* hblocks, int* vblocks) {
     memset(rp, 0, sizeof *rp);
     const size_t ntot = rg_plane_off(p, p.nscales);
     float* xa = c->d_rg;
@@ -446,21 +445,17 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame
     float* cache = xb + 3 * ntot;
     float* hbuf = cache + 6 * ntot;
     rp->nscales = p.nscales;
-    int xb_ = 0, hb_ = 0, vb_ = 0;
+    int hb_ = 0, vb_ = 0;
     size_t poff = 0;
     for (int s = 0; s < p.nscales; ++s) {
-        const size_t n = (size_t)p.w[s] * p.h[s], off = rg_plane_off(p, s);
+        const size_t off = rg_plane_off(p, s);
         rp->w[s] = p.w[s];
         rp->h[s] = p.h[s];
-        xb_ += (int)((n + 255) / 256);
         hb_ += 3 * ((p.h[s] + RG_HL - 1) / RG_HL);
         rp->vgroups[s] = (p.w[s] + RG_VW - 1) / RG_VW;
         vb_ += 3 * rp->vgroups[s];
-        rp->xblk_end[s] = xb_;
         rp->hblk_end[s] = hb_;
         rp->vblk_end[s] = vb_;
-        const float* lin = (ref_frame ? c->d_lin_ref : c->d_lin_dist) + p.lin_off[s];
-        rp->lin[s] = s == 0 ? (const void*)d_frame : (const void*)lin;
         rp->xa[s] = xa + 3 * off;
         rp->xb[s] = xb + 3 * off;
         rp->xout[s] = (ref_frame ? xa : xb) + 3 * off;
@@ -470,7 +465,6 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame
         poff += (size_t)kStats * rp->vgroups[s];
     }
     rp->dump = hbuf + 9 * ntot;
-    *xblocks = xb_;
     *hblocks = hb_;
     *vblocks = vb_;
 }
@@ -502,16 +496,27 @@ void rg_debug_keep_h(ssimu2_ctx* c, const Pyramid& p, const RgPlan& rp, bool ref
                                  n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
 }
 
+// Positive-XYB planes of one frame at every scale, straight from its bytes: the band pyramid with
+// XYB outputs (the recursive modes read nothing but XYB planes; no linear-light level is stored).
+void rg_launch_convert(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, const RgPlan& rp) {
+    const uint8_t* frames[1] = {d_frame};
+    float* none[1] = {nullptr};
+    PyrBandArgs a = pyramid_args(p, 1, frames, none);
+    a.xyb0[0] = rp.xout[0];
+    for (int l = 0; l < a.nlevels; ++l) a.out[0][l] = rp.xout[l + 1];
+    hipLaunchKernelGGL(k_pyramid_bands_xyb, dim3(a.bands_x * a.bands_y), dim3(PYR_THREADS), 0, c->stream, a);
+}
+
 // What depends on the reference alone: its XYB planes and mu1 = blur(x), s11 = blur(x * x) at
 // every scale (the reference's linear pyramid is already enqueued).
 void rg_enqueue_reference(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref) {
     RgPlan rp;
-    int xblocks, hblocks, vblocks;
-    rg_build_plan(c, p, d_ref, true, &rp, &xblocks, &hblocks, &vblocks);
-    if (xblocks == 0) return;  // a frame below 8 x 8 has no scale to score
+    int hblocks, vblocks;
+    rg_build_plan(c, p, true, &rp, &hblocks, &vblocks);
+    if (p.nscales == 0) return;  // a frame below 8 x 8 has no scale to score
     for (int s = 0; s < p.nscales; ++s) rp.emit[s] = rp.cache[s];
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
-    hipLaunchKernelGGL(k_rg_xyb, dim3(xblocks), dim3(256), 0, c->stream, rp);
+    rg_launch_convert(c, p, d_ref, rp);
     if (fma) hipLaunchKernelGGL((k_rg_h<true, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
     else hipLaunchKernelGGL((k_rg_h<false, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
     if (dbg) rg_debug_keep_h(c, p, rp, true);
@@ -523,11 +528,11 @@ void rg_enqueue_reference(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref)
 // {y, y*y, x*y}, maps, final reduction (its linear pyramid is already enqueued).
 int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
     RgPlan rp;
-    int xblocks, hblocks, vblocks;
-    rg_build_plan(c, p, d_dist, false, &rp, &xblocks, &hblocks, &vblocks);
+    int hblocks, vblocks;
+    rg_build_plan(c, p, false, &rp, &hblocks, &vblocks);
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
-    if (xblocks > 0) {  // a frame below 8 x 8 has no scale to score
-        hipLaunchKernelGGL(k_rg_xyb, dim3(xblocks), dim3(256), 0, c->stream, rp);
+    if (p.nscales > 0) {  // a frame below 8 x 8 has no scale to score
+        rg_launch_convert(c, p, d_dist, rp);
         const int lds_h = rg_extra_lds("OAVIF_RG_LDS_H"), lds_v = rg_extra_lds("OAVIF_RG_LDS_V");
         if (fma) hipLaunchKernelGGL((k_rg_h<true, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
         else hipLaunchKernelGGL((k_rg_h<false, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
@@ -570,7 +575,7 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
         if (ref_pyramid_ready && had_ref && !c->have_ref)
             return c->fail(SSIMU2_ERR_NO_REFERENCE, "recursive blur mode: the cached reference was dropped");
     }
-    if (p.nscales > 1) {
+    if (p.nscales > 1 && !recursive) {  // the recursive modes convert straight to XYB planes
         if (ref_pyramid_ready) {
             const uint8_t* frames[1] = {d_dist};
             float* lin[1] = {c->d_lin_dist};
@@ -927,7 +932,7 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
     c->have_ref = false;
     const size_t bytes = (size_t)w * h * 3;
     HIP_TRY(c, hipMemcpyAsync(c->d_ref_u8, ref, bytes, kind, c->stream));
-    if (p.nscales > 1) {  // the reference's linear pyramid, once per search
+    if (p.nscales > 1 && c->blur_mode == SSIMU2_BLUR_FIR) {  // the reference's linear pyramid, once per search
         const uint8_t* frames[1] = {c->d_ref_u8};
         float* lin[1] = {c->d_lin_ref};
         launch_pyramid(c, p, 1, frames, lin);

@@ -172,6 +172,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct PyrBandArgs {
     const uint8_t* in[2];  // frames (tight RGB8)
     float* out[2][5];      // per frame: planes [3][h_l][w_l] of levels 1..5 (entries >= nlevels unused)
+    float* xyb0[2];        // XYB variant only: positive-XYB planes [3][h_0][w_0] of the frame itself
     int w[6], h[6];        // level dimensions, [0] = the 8-bit frame
     int nlevels;           // levels to produce: 1..5; 0 = nothing to do
     int bands_x, bands_y, nframes;
@@ -190,8 +191,20 @@ __device__ __forceinline__ float box4(float p00, float p01, float p10, float p11
     return sum * 0.25f;
 }
 
+// XYB variant (the recursive blur modes, which read nothing but XYB planes): the positive-XYB
+// value of a linear-light pixel goes out instead of the pixel; the linear values stay in
+// registers / LDS for the next level.  linear_to_xyb is what k_rg_xyb applies to the same values.
+__device__ __forceinline__ void pyr_store_xyb(float* out, size_t n, size_t at, const float (&lin)[3]) {
+    float X, Y, B;
+    linear_to_xyb(lin[0], lin[1], lin[2], X, Y, B);
+    out[at] = X;
+    out[n + at] = Y;
+    out[2 * n + at] = B;
+}
+
 // One level from an LDS tile of the level above: `src` is [3][sh][sw] (tile origin = global
 // (2*ox0, 2*oy0) of the level above, whose size is wa x ha), outputs ox0+lx, oy0+ly.
+template <bool XYB>
 __device__ __forceinline__ void pyr_lds_level(const float* src, int sw, int sh, int wa, int ha, float* dst_tile,
                                               int dw_tile, int dh_tile, float* out, int wo, int ho, int ox0,
                                               int oy0, int lx, int ly) {
@@ -205,8 +218,9 @@ __device__ __forceinline__ void pyr_lds_level(const float* src, int sw, int sh, 
         for (int c = 0; c < 3; ++c) {
             const float* p = src + c * sw * sh;
             v[c] = box4(p[ya * sw + xa], p[ya * sw + xb], p[yb * sw + xa], p[yb * sw + xb]);
-            out[c * n + (size_t)oy * wo + ox] = v[c];
+            if (!XYB) out[c * n + (size_t)oy * wo + ox] = v[c];
         }
+        if (XYB) pyr_store_xyb(out, n, (size_t)oy * wo + ox, v);
     }
     if (dst_tile) {
 #pragma unroll
@@ -216,6 +230,7 @@ __device__ __forceinline__ void pyr_lds_level(const float* src, int sw, int sh, 
 
 // `lut`: the sRGB table in LDS; `lds`: PYR_BAND_LDS_FLOATS floats of scratch; 512 threads, all of
 // which must call (barriers inside).  `band` < bands_x * bands_y * nframes.
+template <bool XYB>
 __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, const float* lut, float* lds) {
     const int t = threadIdx.x;
     const int per_frame = a.bands_x * a.bands_y;
@@ -278,10 +293,38 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                 for (int c = 0; c < 3; ++c)
                     l1[j][i][c] = box4(PYR_LIN(2 * j, 2 * i, c), PYR_LIN(2 * j, 2 * i + 1, c),
                                        PYR_LIN(2 * j + 1, 2 * i, c), PYR_LIN(2 * j + 1, 2 * i + 1, c));
-                if (ox < w1 && oy < h1) {
+                if (ox < w1 && oy < h1 && (!XYB || a.nlevels >= 1)) {
                     float* o = a.out[f][0];
+                    if (XYB) {
+                        pyr_store_xyb(o, n1, (size_t)oy * w1 + ox, l1[j][i]);
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = l1[j][i][c];
+                        for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = l1[j][i][c];
+                    }
+                }
+            }
+        }
+        if (XYB) {  // the frame's own XYB planes: this thread's 4 x 4 pixels, a row of four at a time
+            const size_t n0 = (size_t)w0 * h0;
+            float* o = a.xyb0[f];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float px[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    linear_to_xyb(PYR_LIN(j, i, 0), PYR_LIN(j, i, 1), PYR_LIN(j, i, 2), px[0][i], px[1][i], px[2][i]);
+                }
+                if (inside) {
+                    const size_t at = (size_t)(Y0 + j) * w0 + X0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) __builtin_memcpy(o + c * n0 + at, px[c], 16);
+                } else if (Y0 + j < h0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (X0 + i < w0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) o[c * n0 + (size_t)(Y0 + j) * w0 + X0 + i] = px[c][i];
+                        }
                 }
             }
         }
@@ -303,8 +346,9 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                 const float p10 = jb ? l1[1][0][c] : l1[0][0][c];
                 const float p11 = jb ? (ib ? l1[1][1][c] : l1[1][0][c]) : (ib ? l1[0][1][c] : l1[0][0][c]);
                 v[c] = box4(l1[0][0][c], p01, p10, p11);
-                o[c * n2 + (size_t)oy * w2 + ox] = v[c];
+                if (!XYB) o[c * n2 + (size_t)oy * w2 + ox] = v[c];
             }
+            if (XYB) pyr_store_xyb(o, n2, (size_t)oy * w2 + ox, v);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) s2[(c * 8 + ty) * TX + tx] = v[c];
@@ -312,17 +356,17 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
     if (a.nlevels < 3) return;
     __syncthreads();
     if (t < 4 * (TX / 2))
-        pyr_lds_level(s2, TX, 8, a.w[2], a.h[2], s3, TX / 2, 4, a.out[f][2], a.w[3], a.h[3], bx * (TX / 2), by * 4,
+        pyr_lds_level<XYB>(s2, TX, 8, a.w[2], a.h[2], s3, TX / 2, 4, a.out[f][2], a.w[3], a.h[3], bx * (TX / 2), by * 4,
                       t % (TX / 2), t / (TX / 2));
     if (a.nlevels < 4) return;
     __syncthreads();
     if (t < 2 * (TX / 4))
-        pyr_lds_level(s3, TX / 2, 4, a.w[3], a.h[3], s4, TX / 4, 2, a.out[f][3], a.w[4], a.h[4], bx * (TX / 4), by * 2,
+        pyr_lds_level<XYB>(s3, TX / 2, 4, a.w[3], a.h[3], s4, TX / 4, 2, a.out[f][3], a.w[4], a.h[4], bx * (TX / 4), by * 2,
                       t % (TX / 4), t / (TX / 4));
     if (a.nlevels < 5) return;
     __syncthreads();
     if (t < TX / 8)
-        pyr_lds_level(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * (TX / 8), by, t, 0);
+        pyr_lds_level<XYB>(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * (TX / 8), by, t, 0);
 }
 
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands(PyrBandArgs a) {
@@ -330,7 +374,17 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands(PyrBandArgs a) {
     __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
     if (threadIdx.x < 256) s_lut[threadIdx.x] = c_k.lut[threadIdx.x];
     __syncthreads();
-    pyramid_band(a, (int)blockIdx.x, s_lut, s_tiles);
+    pyramid_band<false>(a, (int)blockIdx.x, s_lut, s_tiles);
+}
+
+// The same bands with positive-XYB planes of every level -- the frame's own included -- as the
+// output instead of the linear-light levels: the one conversion launch of the recursive blur modes.
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands_xyb(PyrBandArgs a) {
+    __shared__ float s_lut[256];
+    __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = c_k.lut[threadIdx.x];
+    __syncthreads();
+    pyramid_band<true>(a, (int)blockIdx.x, s_lut, s_tiles);
 }
 
 // ---- fused per-scale kernel, marching form, all scales in one launch ----------------------------

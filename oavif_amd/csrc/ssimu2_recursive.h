@@ -13,7 +13,8 @@
 // before it, so the parallelism is lines x planes x sections and nothing else.  Round 3 layout
 // (all six scales in ONE launch per stage, largest scale first):
 //
-//   k_rg_xyb   positive-XYB planes of one frame, every scale.
+//   k_pyramid_bands_xyb (ssimu2_kernels.h)  positive-XYB planes of one frame at every scale,
+//              straight from its bytes: the band pyramid with XYB outputs, no linear level stored.
 //   k_rg_h     horizontal pass.  One LINE = THREE LANES, one second-order section each; the
 //              published sum (o1 + o3) + o5 is two DPP adds (row_shr:5) per step.  A wave holds
 //              4 DPP rows x 5 lines = 20 image rows (15 of 16 lanes busy); a workgroup is the
@@ -49,9 +50,7 @@ struct RgPlan {
     int hblk_end[kNumScales];     // exclusive end of each scale's workgroups in the k_rg_h grid
     int vblk_end[kNumScales];     // ... in the k_rg_v grid
     int vgroups[kNumScales];      // column groups of a scale = partial sums per statistic
-    int xblk_end[kNumScales];     // ... in the k_rg_xyb grid
-    const void* lin[kNumScales];  // k_rg_xyb input: scale 0 tight RGB8, others fp32 linear planes [3][n]
-    float* xout[kNumScales];      // k_rg_xyb output [3][n]
+    float* xout[kNumScales];      // where the conversion of this plan's frame writes its XYB planes [3][n]
     const float* xa[kNumScales];  // positive-XYB planes of the reference [3][n]
     const float* xb[kNumScales];  // ... of the distorted frame
     float* hbuf[kNumScales];      // horizontal pass: [channel][plane of the pass][n]
@@ -60,38 +59,6 @@ struct RgPlan {
     float* emit[kNumScales];      // k_rg_v_emit target [channel][plane of the pass][n]; null = skip the scale
     float* dump;                  // one row of floats that absorbs the stores of rows outside the image
 };
-
-// ---- XYB planes, every scale in one launch ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rg_xyb(RgPlan p) {
-    int sc = 0, first = 0;
-#pragma unroll
-    for (int s = 0; s < kNumScales - 1; ++s)
-        if (s + 1 < p.nscales && (int)blockIdx.x >= p.xblk_end[s]) {
-            sc = s + 1;
-            first = p.xblk_end[s];
-        }
-    const size_t n = (size_t)p.w[sc] * p.h[sc];
-    const size_t i = (size_t)((int)blockIdx.x - first) * 256 + threadIdx.x;
-    if (i >= n) return;
-    float r, g, b;
-    if (sc == 0) {
-        const uint8_t* q = (const uint8_t*)p.lin[0] + i * 3;
-        r = c_k.lut[q[0]];
-        g = c_k.lut[q[1]];
-        b = c_k.lut[q[2]];
-    } else {
-        const float* q = (const float*)p.lin[sc] + i;
-        r = q[0];
-        g = q[n];
-        b = q[2 * n];
-    }
-    float X, Y, B;
-    linear_to_xyb(r, g, b, X, Y, B);
-    float* out = p.xout[sc];
-    out[i] = X;
-    out[n + i] = Y;
-    out[2 * n + i] = B;
-}
 
 // ---- the recursion --------------------------------------------------------------------------------
 // one step (FastGaussian1D, scalar form):
