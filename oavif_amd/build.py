@@ -54,6 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                    "-fno-slp-vectorize",  # v_pk_*_f32 + operand shuffles are slower than scalar VALU here
                    "-fvisibility=hidden", "-fvisibility-inlines-hidden",  # exports = the headers' functions
                    "-Wall", "-Wno-unused-function", "-o", tmp]
+            cmd += os.environ.get("OAVIF_AMD_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds of experiments
             cmd += [os.path.join(CSRC, s) for s in sources]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
