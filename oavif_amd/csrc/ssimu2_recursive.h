@@ -203,7 +203,7 @@ __device__ __forceinline__ void rg_h_store(const RgLine& L, const RgRing& tout, 
 }
 
 template <bool FMA, int OPK, bool EDGE>
-__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout,
+__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout, float* dump,
                                           rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
     const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
     __builtin_amdgcn_wave_barrier();
@@ -214,18 +214,29 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
     }
     rg_h_fetch<OPK>(L, ra, rb, T + 1);  // lands under this tile's 64 steps
     __builtin_amdgcn_wave_barrier();
+    // 16 columns at a time; the LDS reads of the next 16 are issued before the steps of these 16
+    // (an LDS read takes ~100+ cycles to land; a lone wave per SIMD has nothing else to run)
+    rg_f4 va[2][RG_HT / 4], vb[2][RG_HT / 4];
+#define RG_H_READ(S)                                                                                       \
+    _Pragma("unroll") for (int v = 0; v < RG_HT / 4; ++v) {                                                \
+        va[(S) & 1][v] = *reinterpret_cast<const rg_f4*>(&tin_a[L.line][RG_HT * (S) + 4 * v]);             \
+        if (OPK == 2) vb[(S) & 1][v] = *reinterpret_cast<const rg_f4*>(&tin_b[L.line][RG_HT * (S) + 4 * v]); \
+    }
+    RG_H_READ(0)
 #pragma unroll
     for (int s = 0; s < RG_TW / RG_HT; ++s) {
         float (&c)[RG_HT] = L.cur[s & 1];
         const float (&pv)[RG_HT] = L.cur[(s & 1) ^ 1];
-#pragma unroll
-        for (int v = 0; v < RG_HT / 4; ++v) {
-            const rg_f4 a = *reinterpret_cast<const rg_f4*>(&tin_a[L.line][RG_HT * s + 4 * v]);
-            rg_f4 b = a;
-            if (OPK == 2) b = *reinterpret_cast<const rg_f4*>(&tin_b[L.line][RG_HT * s + 4 * v]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[4 * v + e] = OPK == 0 ? a[e] : a[e] * b[e];
+        if (s + 1 < RG_TW / RG_HT) {
+            RG_H_READ(s + 1)
+            __builtin_amdgcn_sched_barrier(0);  // keep them up here
         }
+#pragma unroll
+        for (int v = 0; v < RG_HT / 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                c[4 * v + e] = OPK == 0 ? va[s & 1][v][e] : OPK == 1 ? va[s & 1][v][e] * va[s & 1][v][e]
+                                                                       : va[s & 1][v][e] * vb[s & 1][v][e];
         if (EDGE) {
 #pragma unroll
             for (int mm = 0; mm < RG_HT; ++mm) c[mm] = T * RG_TW + RG_HT * s + mm < L.w ? c[mm] : 0.0f;
@@ -236,19 +247,24 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
             const float left = mm >= 2 * RG_N ? c[mm - 2 * RG_N] : pv[mm + RG_HT - 2 * RG_N];
             o[mm] = rg_step_lane<FMA>(L.p1, L.p2, left, c[mm], L.n2, L.d1);
         }
-        if (L.holds_out) {  // output columns 64 T - 4 + 16 s ..: ring position = column mod 128
+        // output columns 64 T - 4 + 16 s ..: ring position = column mod 128.  Every lane stores (no
+        // branch around LDS traffic in the middle of the tile): the lanes that do not hold the
+        // line's output write their 16 bytes into a dump row nobody reads (one per workgroup: three
+        // workgroups per CU need the LDS to stay below 53.3 KB).
 #pragma unroll
-            for (int v = 0; v < RG_HT / 4; ++v)
-                *reinterpret_cast<rg_f4*>(&tout[L.line][(T * RG_TW - (RG_N - 1) + RG_HT * s + 4 * v) & (RG_OW - 1)]) =
-                    rg_f4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
+        for (int v = 0; v < RG_HT / 4; ++v) {
+            const int col = (T * RG_TW - (RG_N - 1) + RG_HT * s + 4 * v) & (RG_OW - 1);
+            float* dst = L.holds_out ? &tout[L.line][col] : dump + 4 * (threadIdx.x & 31);
+            *reinterpret_cast<rg_f4*>(dst) = rg_f4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
         }
     }
+#undef RG_H_READ
     __builtin_amdgcn_wave_barrier();
     if (T > 0) rg_h_store<EDGE>(L, tout, T - 1);  // uniform; segment T - 1 is complete now
 }
 
 template <bool FMA, int OPK>
-__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout) {
+__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout, float* dump) {
     const int w = L.w;
     const int ntiles = (w + (RG_N - 1) + RG_TW - 1) / RG_TW;  // steps run to m = w + 3
     // tiles 1 .. nmain - 1 lie inside the row and complete a segment that does (64 (T + 1) <= w)
@@ -258,12 +274,12 @@ __device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_
     for (int k = 0; k < RG_HT; ++k) L.cur[1][k] = 0.0f;  // columns -16 .. -1
     L.p1 = L.p2 = 0.0f;
     rg_h_fetch<OPK>(L, ra, rb, 0);
-    rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, ra, rb, 0);
+    rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, dump, ra, rb, 0);
     int T = 1;
 #pragma unroll 1
-    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin_a, tin_b, tout, ra, rb, T);
+    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin_a, tin_b, tout, dump, ra, rb, T);
 #pragma unroll 1
-    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, ra, rb, T);
+    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, dump, ra, rb, T);
     __builtin_amdgcn_wave_barrier();
     rg_h_store<true>(L, tout, ntiles - 1);  // the row's last columns (w - 1 <= 64 (ntiles - 1) + 59)
 }
@@ -276,10 +292,11 @@ __host__ __device__ __forceinline__ int rg_plane15(bool ref, int ch, int kind) {
 // Horizontal pass.  REF: the planes {x, x*x} of the reference (once per search); otherwise
 // {y, y*y, x*y}.  grid = sum over scales of 3 channels x ceil(h / 20) workgroups of NK waves.
 template <bool FMA, bool REF>
-__global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {
+__global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (capped at 168 VGPRs for 3 waves per SIMD it spills and is slower)
     constexpr int NK = REF ? 2 : 3;
     __shared__ __attribute__((aligned(16))) RgTile s_in[REF ? 2 : 4];
     __shared__ __attribute__((aligned(16))) RgRing s_o[NK];
+    __shared__ __attribute__((aligned(16))) float s_dump[RG_OW];
     int sc = 0, first = 0;
 #pragma unroll
     for (int s = 0; s < kNumScales - 1; ++s)
@@ -313,9 +330,9 @@ __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {
     // REF: x, x*x.  pass: y, y*y, x*y
     L.ga = kind == 2 ? xa : xb;
     L.gb = xb;
-    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_in[0], s_o[0]);
-    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_in[1], s_o[1]);
-    else rg_h_line<FMA, 2>(L, s_in[REF ? 0 : 2], s_in[REF ? 1 : 3], s_o[NK - 1]);
+    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_in[0], s_o[0], s_dump);
+    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_in[1], s_o[1], s_dump);
+    else rg_h_line<FMA, 2>(L, s_in[REF ? 0 : 2], s_in[REF ? 1 : 3], s_o[NK - 1], s_dump);
 }
 
 // ---- vertical pass (+ maps) -----------------------------------------------------------------------
