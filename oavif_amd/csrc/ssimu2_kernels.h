@@ -536,11 +536,24 @@ __device__ __forceinline__ void march_load(uint32_t (&raw)[3], const MarchCursor
     }
 }
 
+// MARCH_LUT_COPIES (experiment): 4 = four interleaved copies of the table,
+// lane & 3 selects the copy.  Measured: no fewer bank conflicts and no faster (a ds_read_b32 serves
+// 32 lanes from 32 banks whichever copy a lane reads); the product uses 1.
+#ifndef MARCH_LUT_COPIES
+#define MARCH_LUT_COPIES 1
+#endif
 __device__ __forceinline__ void march_lut(const float* lut, uint32_t d, uint32_t shift, float (&lin)[3]) {
     d >>= shift;
-    lin[0] = lut[d & 255u];
-    lin[1] = lut[(d >> 8) & 255u];
-    lin[2] = lut[(d >> 16) & 255u];
+    if (MARCH_LUT_COPIES == 1) {
+        lin[0] = lut[d & 255u];
+        lin[1] = lut[(d >> 8) & 255u];
+        lin[2] = lut[(d >> 16) & 255u];
+    } else {
+        const uint32_t k = threadIdx.x & (MARCH_LUT_COPIES - 1);
+        lin[0] = lut[(d & 255u) * MARCH_LUT_COPIES + k];
+        lin[1] = lut[((d >> 8) & 255u) * MARCH_LUT_COPIES + k];
+        lin[2] = lut[((d >> 16) & 255u) * MARCH_LUT_COPIES + k];
+    }
 }
 
 // The converter role of one workgroup: rows 0 .. steps-1 of the segment into the ring, GROUP
@@ -802,7 +815,7 @@ template <int MODE>
 __device__ __forceinline__ void march_body(const MarchPlan& plan) {
     // [row slot][channel][column] of (ref, dist) pairs
     __shared__ __attribute__((aligned(16))) f2 s_ring[RING][3][MRW];
-    __shared__ float s_lut[256];
+    __shared__ float s_lut[256 * MARCH_LUT_COPIES];
     __shared__ double s_part[6][6];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -824,7 +837,9 @@ __device__ __forceinline__ void march_body(const MarchPlan& plan) {
     const int y0 = by * seg_rows;
     const int rows_out = min(seg_rows, h - y0);
     const int steps = rows_out + 2 * RAD;  // input rows y0-4 .. y0+rows_out+3
-    if (u8 && tid < 256) s_lut[tid] = c_k.lut[tid];
+    if (u8) {
+        for (int i = tid; i < 256 * MARCH_LUT_COPIES; i += MARCH_THREADS) s_lut[i] = c_k.lut[i / MARCH_LUT_COPIES];
+    }
     __syncthreads();
 
     const float w0 = c_k.taps[0], w1 = c_k.taps[1], w2 = c_k.taps[2], w3 = c_k.taps[3],
