@@ -142,6 +142,42 @@ void oavif_prescale_8_to_10(const uint8_t* src, size_t n, uint16_t* dst);   /* (
 void oavif_prescale_16_to_10(const uint16_t* src, size_t n, uint16_t* dst); /* v >> 6            io.zig:587 */
 void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v >> 8            io.zig:602 */
 
+/* ---- PNG ingest -------------------------------------------------------
+ *
+ * io.loadPNG (io.zig:242-307) decodes through libspng with these output rules, which decide
+ * what the encoder and the scorer are fed:
+ *     bit depth 16       -> RGBA16, host-endian u16, channels = 4, hbd = true   (io.zig:270-272,292)
+ *     8-bit truecolour   -> RGB8, channels = 3                                   (io.zig:275)
+ *     everything else    -> RGBA8, channels = 4: gray, gray + alpha, palette, RGBA; tRNS becomes
+ *                           alpha, sub-byte gray is scaled to 8 bits             (io.zig:276-280)
+ * and the iCCP profile is handed on decompressed (io.zig:261-268).  These two functions are that
+ * loader without libspng: the PNG specification over zlib (chunk CRCs, the five row filters,
+ * Adam7, PLTE / tRNS / iCCP).  Host code; no GPU involved.
+ *
+ * oavif_png_info_from_memory parses the file and reports the OUTPUT geometry; oavif_png_decode
+ * writes `data_bytes` of pixels (2-byte aligned when hbd) and, if `out_icc` is non-NULL, the
+ * `icc_bytes` of the profile.  Error codes mirror the reference's Zig errors.
+ */
+enum {
+    OAVIF_PNG_OK = 0,
+    OAVIF_PNG_ERR_ARG = -1,    /* null pointer / misaligned u16 output                            */
+    OAVIF_PNG_ERR_HEADER = -2, /* error.GetHeaderFailed: not a PNG, bad IHDR                      */
+    OAVIF_PNG_ERR_DECODE = -3, /* error.DecodeFailed: CRC, chunk order, zlib, filter, palette     */
+    OAVIF_PNG_ERR_SIZE = -4,   /* error.ImageSizeFailed: size overflow, output buffer too small   */
+    OAVIF_PNG_ERR_OOM = -5
+};
+typedef struct {
+    uint32_t width, height;
+    uint32_t channels;   /* of the OUTPUT: 3 or 4 (io.zig:287-290)                     */
+    int hbd;             /* 1 = the output is u16 per sample (16-bit source)           */
+    size_t data_bytes;   /* width * height * channels * (hbd ? 2 : 1)                  */
+    size_t icc_bytes;    /* decompressed iCCP profile, 0 = none                        */
+    uint32_t bit_depth, color_type, interlaced; /* of the file (IHDR)                 */
+} oavif_png_info;
+int oavif_png_info_from_memory(const uint8_t* png, size_t len, oavif_png_info* out);
+int oavif_png_decode(const uint8_t* png, size_t len, uint8_t* out_pixels, size_t out_cap, uint8_t* out_icc,
+                     size_t icc_cap);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

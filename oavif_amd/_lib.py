@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "oavif_tq_interpolate_quantizer", "oavif_tq_find_target_quality", "oavif_tq_search_hip",
     "oavif_tq_find_target_quality_speculative",
     "oavif_prescale_8_to_10", "oavif_prescale_16_to_10", "oavif_prescale_16_to_8",
+    "oavif_png_info_from_memory", "oavif_png_decode",
 )
 
 
@@ -58,6 +59,12 @@ class TQResult(ctypes.Structure):
     _fields_ = [("q", ctypes.c_uint32), ("score", ctypes.c_double),
                 ("num_pass", ctypes.c_uint32), ("buf_q", ctypes.c_int32),
                 ("history_len", ctypes.c_uint32), ("history", TQPass * TQ_MAX_PASS)]
+
+
+class PngInfo(ctypes.Structure):   # oavif_png_info (include/oavif_tq.h)
+    _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("channels", ctypes.c_uint32),
+                ("hbd", ctypes.c_int), ("data_bytes", ctypes.c_size_t), ("icc_bytes", ctypes.c_size_t),
+                ("bit_depth", ctypes.c_uint32), ("color_type", ctypes.c_uint32), ("interlaced", ctypes.c_uint32)]
 
 
 class TQSpecOptions(ctypes.Structure):
@@ -195,6 +202,11 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
     L.oavif_prescale_16_to_10.restype = None
     L.oavif_prescale_16_to_8.argtypes = [u16p, ctypes.c_size_t, u8p]
     L.oavif_prescale_16_to_8.restype = None
+    if hasattr(L, "oavif_png_decode"):   # absent from older builds (scripts/gpu_ab.py loads those too)
+        L.oavif_png_info_from_memory.argtypes = [u8p, ctypes.c_size_t, ctypes.POINTER(PngInfo)]
+        L.oavif_png_info_from_memory.restype = ci
+        L.oavif_png_decode.argtypes = [u8p, ctypes.c_size_t, vp, ctypes.c_size_t, vp, ctypes.c_size_t]
+        L.oavif_png_decode.restype = ci
     L.oavif_tq_search_hip.argtypes = [ctypes.POINTER(TQOptions), vp, u8p, u32, u32, CODEC_FN, vp,
                                       ctypes.POINTER(TQResult), ctypes.POINTER(ctypes.c_size_t)]
     L.oavif_tq_search_hip.restype = ci

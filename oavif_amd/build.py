@@ -15,8 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip.so")              # the product: C ABI of include/ssimu2_hip.h, oavif_tq.h
 INSTR_LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip_instr.so")  # + include/ssimu2_hip_internal.h (bench / tests only)
-SOURCES = ["ssimu2_hip.hip", "tq.cpp"]
-INSTR_SOURCES = ["ssimu2_instrument.hip", "tq.cpp"]  # ssimu2_instrument.hip includes ssimu2_hip.hip
+SOURCES = ["ssimu2_hip.hip", "tq.cpp", "png_ingest.cpp"]
+INSTR_SOURCES = ["ssimu2_instrument.hip", "tq.cpp", "png_ingest.cpp"]  # ssimu2_instrument.hip includes ssimu2_hip.hip
 
 
 def _hipcc() -> str:
@@ -56,6 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                    "-Wall", "-Wno-unused-function", "-o", tmp]
             cmd += os.environ.get("OAVIF_AMD_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds of experiments
             cmd += [os.path.join(CSRC, s) for s in sources]
+            cmd += ["-lz"]  # png_ingest.cpp inflates with zlib
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             try:

@@ -252,6 +252,16 @@ def load_source(path: str) -> Source:
         data, w, h, ch = load_pam(open(path, "rb").read())
         arr = np.frombuffer(data, np.uint8).reshape(h, w, ch)
         hbd = False
+    elif ext == ".png":
+        # io.loadPNG (io.zig:242-307) through the native decoder of the C ABI (oavif_png_decode):
+        # 16-bit -> RGBA16 + hbd, 8-bit truecolour -> RGB8, everything else -> RGBA8
+        from .png import PngError, load_png
+        try:
+            arr, _ch, hbd, icc = load_png(open(path, "rb").read())
+        except PngError as e:
+            raise CliError(e.name)
+        if hbd:   # the stand-in encoder is 8-bit: hand it what Image.toRGB8 makes of 16 bits (>> 8)
+            arr = (arr >> 8).astype(np.uint8)
     else:
         im = Image.open(path)
         hbd = im.mode in ("I;16", "I;16B", "I;16L", "I")

@@ -1,0 +1,371 @@
+// PNG ingest with the output rules of oavif's loader.
+//
+//   /root/reference/src/io.zig:242-307  loadPNG: libspng, decode flags 0, output format chosen as
+//       bit depth 16               -> SPNG_FMT_RGBA16  (host-endian u16, 4 channels, hbd = true)
+//       8-bit truecolour           -> SPNG_FMT_RGB8    (3 channels)
+//       everything else            -> SPNG_FMT_RGBA8   (4 channels: gray / gray+alpha / palette /
+//                                     RGBA; tRNS becomes alpha; sub-byte gray scaled to 8 bits)
+//   and the iCCP profile, decompressed, handed on unchanged (io.zig:261-268).
+//
+// libspng is not in this image and is third-party anyway; this is the PNG specification
+// (signature, chunk CRCs, IHDR / PLTE / tRNS / iCCP / IDAT, zlib inflate, the five row filters,
+// Adam7) written against zlib alone.  Critical chunks with a bad CRC fail the decode, ancillary
+// ones are skipped (libspng's defaults).  No gamma handling (flags 0).  Host-side code: no HIP.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/oavif_tq.h"
+
+namespace {
+
+inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+inline uint16_t be16(const uint8_t* p) { return (uint16_t)(p[0] << 8 | p[1]); }
+
+struct Span {
+    const uint8_t* p;
+    size_t n;
+};
+
+struct Png {
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    Span plte{nullptr, 0}, trns{nullptr, 0}, iccp{nullptr, 0};
+    std::vector<Span> idat;
+    int samples() const { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4; }
+    int bits_per_pixel() const { return samples() * depth; }
+    bool hbd() const { return depth == 16; }
+    uint32_t out_channels() const { return hbd() ? 4u : (ctype == 2 ? 3u : 4u); }
+};
+
+// chunk walk; returns an oavif_png error code
+int parse(const uint8_t* buf, size_t len, Png& png) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (len < 8 + 25 || memcmp(buf, sig, 8) != 0) return OAVIF_PNG_ERR_HEADER;
+    size_t pos = 8;
+    bool first = true, seen_idat = false, idat_closed = false, end = false;
+    while (!end) {
+        if (len - pos < 12) return first ? OAVIF_PNG_ERR_HEADER : OAVIF_PNG_ERR_DECODE;
+        const uint32_t clen = be32(buf + pos);
+        const uint8_t* type = buf + pos + 4;
+        if (clen > 0x7FFFFFFFu || (size_t)clen > len - pos - 12) return first ? OAVIF_PNG_ERR_HEADER : OAVIF_PNG_ERR_DECODE;
+        const uint8_t* data = type + 4;
+        const bool critical = !(type[0] & 0x20);
+        const bool crc_ok = (uint32_t)crc32(crc32(0L, type, 4), data, clen) == be32(data + clen);
+        pos += 12 + (size_t)clen;
+        if (first) {
+            if (memcmp(type, "IHDR", 4) != 0 || clen != 13 || !crc_ok) return OAVIF_PNG_ERR_HEADER;
+            png.w = be32(data);
+            png.h = be32(data + 4);
+            png.depth = data[8];
+            png.ctype = data[9];
+            png.interlace = data[12];
+            if (png.w == 0 || png.h == 0 || png.w > 0x7FFFFFFFu || png.h > 0x7FFFFFFFu) return OAVIF_PNG_ERR_HEADER;
+            if (data[10] != 0 || data[11] != 0 || png.interlace > 1) return OAVIF_PNG_ERR_HEADER;
+            const int d = png.depth;
+            bool ok = false;
+            switch (png.ctype) {
+                case 0: ok = d == 1 || d == 2 || d == 4 || d == 8 || d == 16; break;
+                case 3: ok = d == 1 || d == 2 || d == 4 || d == 8; break;
+                case 2: case 4: case 6: ok = d == 8 || d == 16; break;
+                default: ok = false;
+            }
+            if (!ok) return OAVIF_PNG_ERR_HEADER;
+            first = false;
+            continue;
+        }
+        if (!crc_ok) {
+            if (critical) return OAVIF_PNG_ERR_DECODE;
+            continue;  // ancillary chunk with a bad CRC: discarded
+        }
+        if (memcmp(type, "IDAT", 4) == 0) {
+            if (idat_closed) return OAVIF_PNG_ERR_DECODE;  // IDAT chunks must be consecutive
+            seen_idat = true;
+            png.idat.push_back(Span{data, clen});
+            continue;
+        }
+        if (seen_idat) idat_closed = true;
+        if (memcmp(type, "IEND", 4) == 0) {
+            end = true;
+        } else if (memcmp(type, "PLTE", 4) == 0) {
+            if (seen_idat || clen == 0 || clen % 3 != 0 || clen > 768) return OAVIF_PNG_ERR_DECODE;
+            png.plte = Span{data, clen};
+        } else if (memcmp(type, "tRNS", 4) == 0) {
+            if (!seen_idat) png.trns = Span{data, clen};
+        } else if (memcmp(type, "iCCP", 4) == 0) {
+            if (!seen_idat && !png.plte.p) png.iccp = Span{data, clen};
+        } else if (critical) {
+            return OAVIF_PNG_ERR_DECODE;  // unknown critical chunk
+        }
+    }
+    if (png.idat.empty()) return OAVIF_PNG_ERR_DECODE;
+    if (png.ctype == 3 && !png.plte.p) return OAVIF_PNG_ERR_DECODE;
+    // tRNS must fit its colour type; a malformed one is ignored like any bad ancillary chunk
+    if (png.trns.p) {
+        const size_t want = png.ctype == 0 ? 2 : png.ctype == 2 ? 6 : 0;
+        if (png.ctype == 4 || png.ctype == 6 || (png.ctype != 3 && png.trns.n != want) ||
+            (png.ctype == 3 && png.trns.n > png.plte.n / 3))
+            png.trns = Span{nullptr, 0};
+    }
+    return OAVIF_PNG_OK;
+}
+
+// iCCP: keyword (1-79 bytes) NUL, compression method 0, zlib stream
+int inflate_icc(const Png& png, std::vector<uint8_t>& out) {
+    out.clear();
+    if (!png.iccp.p) return OAVIF_PNG_OK;
+    const uint8_t* p = png.iccp.p;
+    size_t k = 0;
+    while (k < png.iccp.n && k < 80 && p[k]) ++k;
+    if (k == 0 || k >= 80 || k + 2 > png.iccp.n || p[k + 1] != 0) return OAVIF_PNG_OK;  // malformed: no profile
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit(&zs) != Z_OK) return OAVIF_PNG_ERR_OOM;
+    zs.next_in = const_cast<uint8_t*>(p + k + 2);
+    zs.avail_in = (uInt)(png.iccp.n - k - 2);
+    uint8_t chunk[16384];
+    int rc = Z_OK;
+    while (rc == Z_OK) {
+        zs.next_out = chunk;
+        zs.avail_out = sizeof chunk;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        if (rc == Z_OK || rc == Z_STREAM_END) {
+            try {
+                out.insert(out.end(), chunk, chunk + (sizeof chunk - zs.avail_out));
+            } catch (...) {
+                inflateEnd(&zs);
+                return OAVIF_PNG_ERR_OOM;
+            }
+        }
+        if (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) break;  // truncated stream
+    }
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) out.clear();  // a broken profile is dropped, not fatal (ancillary)
+    return OAVIF_PNG_OK;
+}
+
+inline uint8_t paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (uint8_t)(pa <= pb && pa <= pc ? a : (pb <= pc ? b : c));
+}
+
+// undo the filter of one row in place; `prev` = the unfiltered row above (zeros for a pass's first row)
+int unfilter(int ftype, uint8_t* row, const uint8_t* prev, size_t n, size_t bpp) {
+    switch (ftype) {
+        case 0: return 0;
+        case 1:
+            for (size_t i = bpp; i < n; ++i) row[i] = (uint8_t)(row[i] + row[i - bpp]);
+            return 0;
+        case 2:
+            for (size_t i = 0; i < n; ++i) row[i] = (uint8_t)(row[i] + prev[i]);
+            return 0;
+        case 3:
+            for (size_t i = 0; i < n; ++i) {
+                const int a = i >= bpp ? row[i - bpp] : 0;
+                row[i] = (uint8_t)(row[i] + ((a + prev[i]) >> 1));
+            }
+            return 0;
+        case 4:
+            for (size_t i = 0; i < n; ++i) {
+                const int a = i >= bpp ? row[i - bpp] : 0, c = i >= bpp ? prev[i - bpp] : 0;
+                row[i] = (uint8_t)(row[i] + paeth(a, prev[i], c));
+            }
+            return 0;
+        default: return -1;
+    }
+}
+
+// sample s (0-based, across the row) of an unfiltered row, for depth <= 8
+inline unsigned sample8(const uint8_t* row, size_t s, int depth) {
+    if (depth == 8) return row[s];
+    const size_t bit = s * (size_t)depth;
+    return (row[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1u << depth) - 1u);
+}
+
+struct Expander {
+    const Png& png;
+    uint8_t* out;  // RGB8 / RGBA8 / RGBA16 (host-endian)
+    // one pixel of an unfiltered row -> the output pixel (x, y); returns false on a bad palette index
+    bool put(const uint8_t* row, size_t i, uint32_t x, uint32_t y) const {
+        const size_t at = (size_t)y * png.w + x;
+        const int d = png.depth;
+        if (png.hbd()) {
+            uint16_t* o = reinterpret_cast<uint16_t*>(out) + at * 4;
+            const uint8_t* p = row + i * (size_t)png.samples() * 2;
+            uint16_t r, g, b, a = 0xFFFF;
+            switch (png.ctype) {
+                case 0:
+                    r = g = b = be16(p);
+                    if (png.trns.p && r == be16(png.trns.p)) a = 0;
+                    break;
+                case 4:
+                    r = g = b = be16(p);
+                    a = be16(p + 2);
+                    break;
+                case 2:
+                    r = be16(p), g = be16(p + 2), b = be16(p + 4);
+                    if (png.trns.p && r == be16(png.trns.p) && g == be16(png.trns.p + 2) && b == be16(png.trns.p + 4)) a = 0;
+                    break;
+                default:
+                    r = be16(p), g = be16(p + 2), b = be16(p + 4), a = be16(p + 6);
+            }
+            o[0] = r, o[1] = g, o[2] = b, o[3] = a;
+            return true;
+        }
+        if (png.ctype == 2) {  // RGB8: copied as it is (no alpha in this output format, tRNS unused)
+            memcpy(out + at * 3, row + i * 3, 3);
+            return true;
+        }
+        uint8_t* o = out + at * 4;
+        switch (png.ctype) {
+            case 0: {
+                const unsigned v = sample8(row, i, d);
+                const uint8_t g = (uint8_t)(d == 8 ? v : v * (255u / ((1u << d) - 1u)));
+                o[0] = o[1] = o[2] = g;
+                o[3] = (png.trns.p && v == (unsigned)(be16(png.trns.p) & ((1u << d) - 1u))) ? 0 : 255;
+                return true;
+            }
+            case 3: {
+                const unsigned idx = sample8(row, i, d);
+                if ((size_t)idx * 3 + 2 >= png.plte.n) return false;
+                memcpy(o, png.plte.p + idx * 3, 3);
+                o[3] = idx < png.trns.n ? png.trns.p[idx] : 255;
+                return true;
+            }
+            case 4:
+                o[0] = o[1] = o[2] = row[i * 2];
+                o[3] = row[i * 2 + 1];
+                return true;
+            default:
+                memcpy(o, row + i * 4, 4);
+                return true;
+        }
+    }
+};
+
+size_t row_bytes(const Png& png, uint32_t w) { return ((size_t)w * (size_t)png.bits_per_pixel() + 7) / 8; }
+
+struct Pass {
+    uint32_t x0, y0, dx, dy;
+};
+const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+
+}  // namespace
+
+extern "C" {
+
+int oavif_png_info_from_memory(const uint8_t* png_bytes, size_t len, oavif_png_info* out) {
+    if (!png_bytes || !out) return OAVIF_PNG_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    Png png;
+    int rc;
+    try {
+        rc = parse(png_bytes, len, png);
+    } catch (...) {
+        return OAVIF_PNG_ERR_OOM;
+    }
+    if (rc) return rc;
+    const uint64_t px = (uint64_t)png.w * png.h;
+    const uint64_t bytes = px * png.out_channels() * (png.hbd() ? 2u : 1u);
+    if (px > (1ull << 40) || bytes / png.out_channels() / (png.hbd() ? 2u : 1u) != px || bytes > (uint64_t)SIZE_MAX / 2)
+        return OAVIF_PNG_ERR_SIZE;
+    std::vector<uint8_t> icc;
+    if ((rc = inflate_icc(png, icc))) return rc;
+    out->width = png.w;
+    out->height = png.h;
+    out->channels = png.out_channels();
+    out->hbd = png.hbd() ? 1 : 0;
+    out->data_bytes = (size_t)bytes;
+    out->icc_bytes = icc.size();
+    out->bit_depth = (uint32_t)png.depth;
+    out->color_type = (uint32_t)png.ctype;
+    out->interlaced = (uint32_t)png.interlace;
+    return OAVIF_PNG_OK;
+}
+
+int oavif_png_decode(const uint8_t* png_bytes, size_t len, uint8_t* out_pixels, size_t out_cap, uint8_t* out_icc,
+                     size_t icc_cap) {
+    if (!png_bytes || !out_pixels) return OAVIF_PNG_ERR_ARG;
+    oavif_png_info info;
+    int rc = oavif_png_info_from_memory(png_bytes, len, &info);
+    if (rc) return rc;
+    if (out_cap < info.data_bytes || (info.icc_bytes && out_icc && icc_cap < info.icc_bytes)) return OAVIF_PNG_ERR_SIZE;
+    if (info.hbd && (reinterpret_cast<uintptr_t>(out_pixels) & 1u)) return OAVIF_PNG_ERR_ARG;  // u16 output
+    try {
+        Png png;
+        if ((rc = parse(png_bytes, len, png))) return rc;
+        if (out_icc && info.icc_bytes) {
+            std::vector<uint8_t> icc;
+            if ((rc = inflate_icc(png, icc))) return rc;
+            memcpy(out_icc, icc.data(), icc.size());
+        }
+        // filtered scanlines of every pass: 1 filter byte + the row
+        size_t need = 0;
+        uint32_t pw[7], ph[7];
+        const int npass = png.interlace ? 7 : 1;
+        for (int k = 0; k < npass; ++k) {
+            if (png.interlace) {
+                const Pass& a = kAdam7[k];
+                pw[k] = png.w > a.x0 ? (png.w - a.x0 + a.dx - 1) / a.dx : 0;
+                ph[k] = png.h > a.y0 ? (png.h - a.y0 + a.dy - 1) / a.dy : 0;
+            } else {
+                pw[k] = png.w;
+                ph[k] = png.h;
+            }
+            if (pw[k] && ph[k]) need += (size_t)ph[k] * (1 + row_bytes(png, pw[k]));
+        }
+        std::vector<uint8_t> raw(need);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) return OAVIF_PNG_ERR_OOM;
+        zs.next_out = raw.data();
+        size_t produced = 0;
+        int zrc = Z_OK;
+        for (size_t c = 0; c < png.idat.size() && zrc == Z_OK; ++c) {
+            zs.next_in = const_cast<uint8_t*>(png.idat[c].p);
+            zs.avail_in = (uInt)png.idat[c].n;
+            while (zs.avail_in && zrc == Z_OK) {
+                const size_t room = need - produced;
+                zs.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
+                const size_t before = zs.avail_out;
+                zrc = inflate(&zs, Z_NO_FLUSH);
+                produced += before - zs.avail_out;
+                zs.next_out = raw.data() + produced;
+                if (produced == need && zrc == Z_OK) zrc = Z_STREAM_END;  // trailing data is ignored
+            }
+        }
+        inflateEnd(&zs);
+        if (produced != need || (zrc != Z_STREAM_END && zrc != Z_OK)) return OAVIF_PNG_ERR_DECODE;
+        const size_t bpp = (size_t)(png.bits_per_pixel() + 7) / 8;
+        const Expander ex{png, out_pixels};
+        size_t off = 0;
+        std::vector<uint8_t> zero;
+        for (int k = 0; k < npass; ++k) {
+            if (!pw[k] || !ph[k]) continue;
+            const size_t rb = row_bytes(png, pw[k]);
+            zero.assign(rb, 0);
+            const uint8_t* prev = zero.data();
+            const Pass a = png.interlace ? kAdam7[k] : Pass{0, 0, 1, 1};
+            for (uint32_t j = 0; j < ph[k]; ++j) {
+                uint8_t* row = raw.data() + off + 1;
+                if (unfilter(raw[off], row, prev, rb, bpp)) return OAVIF_PNG_ERR_DECODE;
+                const uint32_t y = a.y0 + j * a.dy;
+                for (uint32_t i = 0; i < pw[k]; ++i)
+                    if (!ex.put(row, i, a.x0 + i * a.dx, y)) return OAVIF_PNG_ERR_DECODE;
+                prev = row;
+                off += 1 + rb;
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return OAVIF_PNG_ERR_OOM;
+    } catch (...) {
+        return OAVIF_PNG_ERR_DECODE;
+    }
+    return OAVIF_PNG_OK;
+}
+
+}  // extern "C"

@@ -1,7 +1,9 @@
 """CPU-only sanitizer builds of the host-side native code (no sanitizer exists for the GPU on
 this pool): the search logic of oavif_amd/csrc/tq.cpp under ASan + UBSan and under TSan (its
 speculative search hands probe waves to caller threads), and the CPU checker oracle/ssimu2_oracle.c
-under ASan + UBSan.  The harnesses are tests/c/tq_sanitize.cpp and tests/c/oracle_sanitize.c."""
+under ASan + UBSan, and the native PNG ingest (oavif_amd/csrc/png_ingest.cpp) under ASan + UBSan
+with thousands of corrupted files.  The harnesses are tests/c/tq_sanitize.cpp,
+tests/c/oracle_sanitize.c and tests/c/png_sanitize.cpp."""
 import os
 import shutil
 import subprocess
@@ -12,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INC = os.path.join(ROOT, "include")
 TQ = os.path.join(ROOT, "oavif_amd", "csrc", "tq.cpp")
 ORACLE = os.path.join(ROOT, "oracle", "ssimu2_oracle.c")
+PNG = os.path.join(ROOT, "oavif_amd", "csrc", "png_ingest.cpp")
 
 
 def _run(cmd, exe, args=(), env=None):
@@ -40,3 +43,16 @@ def test_oracle_is_clean_under_sanitizers(tmp_path):
                 "-ffp-contract=off", ORACLE, os.path.join(ROOT, "tests", "c", "oracle_sanitize.c"),
                 "-o", exe, "-lm"], exe)
     assert "oracle_sanitize ok" in out
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_png_ingest_survives_corrupted_files_under_sanitizers(tmp_path):
+    """Untrusted input: 24 valid seed files (every colour type / depth, with and without Adam7) and
+    7,200 corruptions of them -- truncations, bit flips, bit flips with the chunk CRC repaired so
+    that they reach the zlib / filter / palette code -- must each end in an error code or a clean
+    decode, with no ASan / UBSan report."""
+    exe = str(tmp_path / "png_san")
+    out = _run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                "-I", INC, PNG, os.path.join(ROOT, "tests", "c", "png_sanitize.cpp"), "-o", exe, "-lz"],
+               exe, ["300"])
+    assert "png_sanitize ok" in out
