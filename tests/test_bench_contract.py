@@ -91,3 +91,18 @@ def test_bench_byte_model_matches_survey():
         w, h = (w + 1) // 2, (h + 1) // 2
         px += w * h
     assert abs((85.97 - consts["ALGO_BYTES_PER_PX_MARCH"]) - 24 * px / (3840 * 2160)) < 0.01
+
+
+def test_round3_fields_repeated_timing_and_the_recursive_modes_pass():
+    """the K-step block is timed repeatedly (>= 0.2 s of timed wall, median reported,
+    spread printed); no stream calibration in the bench; the recursive blur mode reports its
+    per-pass cost with a cached reference, under 0.5 ms at 4K, with the pair score's bits."""
+    d = _line()
+    assert d["repeats"] >= 1 and d["timed_region_s"] >= 0.2
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert "stream_pair_calibration" not in d and d["config"]["streams_per_gpu"] == 2
+    r = d["recursive_blur_mode"]
+    assert r["cached_reference"]["bit_identical_to_pair_score"] is True
+    assert r["cached_reference"]["ms_per_pass"] <= 0.5 < 2 * r["ms_per_score"]
+    assert r["device_memory_MB"]["reference_cache"] + r["device_memory_MB"]["per_pass_scratch"] < 1000
+    assert d["roofline"]["counters"]["stale"] is False
