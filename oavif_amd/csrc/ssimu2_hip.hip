@@ -12,9 +12,13 @@
 //   partials    : fp64 [scale][18 stats][workgroups] partial sums
 //   result      : fp64 [108 averages][score][nscales], mirrored in pinned host memory
 //
+//   SSIMU2_BLUR_RECURSIVE modes only (ssimu2_recursive.h), every scale packed: XYB planes of both
+//   frames, the reference's cached blur(x) / blur(x*x) planes, the horizontal pass of a pass's planes
+//
 // One score = ONE k_pyramid_bands launch (all five levels), ONE k_march launch covering all six scales, one
-// k_finalize launch, one 880-byte D2H copy; everything on the ctx stream, no host sync
-// inside (enqueue / wait split).
+// k_finalize launch, one 880-byte D2H copy (recursive modes: conversion, horizontal pass, vertical
+// pass + maps, k_finalize); everything on the ctx stream, no host sync inside (enqueue / wait
+// split).  Streams the library creates are placed on distinct hardware queues ("stream placement").
 #include <hip/hip_runtime.h>
 
 #include <math.h>
