@@ -116,6 +116,12 @@ typedef int (*oavif_tq_batch_probe_fn)(void* user, const uint32_t* qs, uint32_t 
 
 typedef struct {
     uint32_t max_fanout; /* probes per wave, 1..OAVIF_TQ_MAX_FANOUT; 1 = the sequential search */
+    /* Probes of the FIRST wave, 1..max_fanout; 0 = max_fanout.  The first probe of a search is the
+       model's guess (tq.zig:40-43), and many searches end on it: with 1 the first wave is that
+       probe alone, so a one-pass search costs exactly what the sequential search costs (no extra
+       encodes competing for the host's cores), and speculation starts with the second wave, when
+       there is a measured score to extrapolate from. */
+    uint32_t first_wave_fanout;
 } oavif_tq_spec_options;
 
 typedef struct {

@@ -68,7 +68,7 @@ class PngInfo(ctypes.Structure):   # oavif_png_info (include/oavif_tq.h)
 
 
 class TQSpecOptions(ctypes.Structure):
-    _fields_ = [("max_fanout", ctypes.c_uint32)]
+    _fields_ = [("max_fanout", ctypes.c_uint32), ("first_wave_fanout", ctypes.c_uint32)]
 
 
 class TQSpecStats(ctypes.Structure):

@@ -194,7 +194,8 @@ namespace {
 // ---- speculative probe fan-out -------------------------------------------------------------
 struct Spec {
     const oavif_tq_options* o;
-    uint32_t fanout;
+    uint32_t fanout;        // probes per wave from the second wave on
+    uint32_t first_fanout;  // ... of the first wave
     oavif_tq_batch_probe_fn batch;
     void* user;
     bool known[101];
@@ -246,14 +247,14 @@ static double estimate_score(const Spec& s, uint32_t q) {
 
 // Candidates for the pass after `q_miss`: what the search would ask for next if q_miss scored
 // est +- (tolerance + 0.5 + k), k = 0, 1, 2, ...  (inside the tolerance the search ends).
-static void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n) {
+static void add_candidates(const Spec& s, uint32_t q_miss, uint32_t* wave, uint32_t* n, uint32_t fanout) {
     const double est = estimate_score(s, q_miss);
-    for (int k = 0; k < 24 && *n < s.fanout; ++k) {
-        for (int sign = +1; sign >= -1 && *n < s.fanout; sign -= 2) {
+    for (int k = 0; k < 24 && *n < fanout; ++k) {
+        for (int sign = +1; sign >= -1 && *n < fanout; sign -= 2) {
             Sim m{&s, q_miss, est + sign * (s.o->tolerance + 0.5 + k), -1};
             // hypothetical scores relative to the TARGET as well: the pass-0 bounds depend on
             // |score - target| only, and the estimate may be far off for unusual content
-            for (int rel = 0; rel < 2 && *n < s.fanout; ++rel) {
+            for (int rel = 0; rel < 2 && *n < fanout; ++rel) {
                 if (rel == 1) m.hyp = s.o->score_tgt + sign * (s.o->tolerance + 0.5 + k);
                 m.next = -1;
                 oavif_tq_result tmp;
@@ -279,7 +280,8 @@ static int replay_probe(void* p, uint32_t q, double* out_score) {
     double sc[OAVIF_TQ_MAX_FANOUT];
     uint32_t n = 0;
     wave[n++] = q;
-    if (s->fanout > 1) add_candidates(*s, q, wave, &n);
+    const uint32_t fanout = s->stats.waves == 0 ? s->first_fanout : s->fanout;
+    if (fanout > 1) add_candidates(*s, q, wave, &n, fanout);
     const int rc = s->batch(s->user, wave, n, sc);
     if (rc != 0) return rc;
     s->stats.waves += 1;
@@ -316,9 +318,11 @@ int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
                                              oavif_tq_result* out, oavif_tq_spec_stats* stats) {
     if (!o || !so || !batch || !out) return SSIMU2_ERR_INVALID_ARG;
     if (so->max_fanout < 1 || so->max_fanout > OAVIF_TQ_MAX_FANOUT) return SSIMU2_ERR_INVALID_ARG;
+    if (so->first_wave_fanout > so->max_fanout) return SSIMU2_ERR_INVALID_ARG;
     Spec s{};
     s.o = o;
     s.fanout = so->max_fanout;
+    s.first_fanout = so->first_wave_fanout ? so->first_wave_fanout : so->max_fanout;
     s.batch = batch;
     s.user = user;
     const int rc = oavif_tq_find_target_quality(o, replay_probe, &s, out);

@@ -82,10 +82,12 @@ class SpecStats:
 
 def find_target_quality_speculative(batch_probe: Callable[[List[int]], List[float]],
                                     score_tgt: float = 80.0, tolerance: float = 2.0,
-                                    max_pass: int = 6, max_fanout: int = 4):
+                                    max_pass: int = 6, max_fanout: int = 4, first_wave_fanout: int = 0):
     """`findTargetQuality` with several probes in flight (include/oavif_tq.h, "speculative probe
     fan-out").  batch_probe(qs) -> scores probes the quantizers of one wave, qs[0] being the one
-    the search waits for.  -> (TQResult, SpecStats); the TQResult equals the sequential one."""
+    the search waits for.  `first_wave_fanout`: probes of the first wave (0 = max_fanout; 1 = the
+    model's guess alone, so a one-pass search costs what the sequential search costs).
+    -> (TQResult, SpecStats); the TQResult equals the sequential one."""
     L = _lib.lib()
     err: list = []
 
@@ -106,7 +108,7 @@ def find_target_quality_speculative(batch_probe: Callable[[List[int]], List[floa
     res = _lib.TQResult()
     stats = _lib.TQSpecStats()
     opts = _options(score_tgt, tolerance, max_pass)
-    so = _lib.TQSpecOptions(int(max_fanout))
+    so = _lib.TQSpecOptions(int(max_fanout), int(first_wave_fanout))
     rc = L.oavif_tq_find_target_quality_speculative(ctypes.byref(opts), ctypes.byref(so), cb, None,
                                                     ctypes.byref(res), ctypes.byref(stats))
     if err:
@@ -118,11 +120,15 @@ def find_target_quality_speculative(batch_probe: Callable[[List[int]], List[floa
 
 def search_speculative_hip(scorers, ref_rgb: np.ndarray,
                            codec: Callable[[int], Tuple[np.ndarray, int]], score_tgt: float = 80.0,
-                           tolerance: float = 2.0, max_pass: int = 6, max_fanout: int | None = None):
+                           tolerance: float = 2.0, max_pass: int = 6, max_fanout: int | None = None,
+                           first_wave_fanout: int = 1):
     """One search with its probes fanned over `scorers` (one context = one HIP stream each, same
     device) and as many host threads: every probe of a wave runs codec(q) -- the CPU encode +
     decode -- and scores its frame on its own context, so the GPU work of one probe overlaps the
-    CPU work of the others (BASELINE configs[2]).  -> (TQResult, SpecStats, {q: avif size})."""
+    CPU work of the others (BASELINE configs[2]).  The first wave is the model's guess alone by
+    default (`first_wave_fanout=1`): searches that end on their first pass -- most, on typical
+    content -- then cost exactly a sequential search, and speculation starts with the second wave.
+    -> (TQResult, SpecStats, {q: avif size})."""
     from concurrent.futures import ThreadPoolExecutor
     scorers = list(scorers)
     if not scorers:
@@ -131,12 +137,14 @@ def search_speculative_hip(scorers, ref_rgb: np.ndarray,
     if fan > len(scorers):
         raise ValueError("max_fanout exceeds the number of scorer contexts")
     ref = np.ascontiguousarray(ref_rgb, dtype=np.uint8)
-    for s in scorers[:fan]:
-        s.set_reference(ref)
-    sizes: dict = {}
+    have_ref = [False] * fan   # a context gets the reference when a wave first uses it: a search that
+    sizes: dict = {}           # ends on its first (one-probe) wave uploads it once, like the sequential one
 
     def one(args):
         slot, q = args
+        if not have_ref[slot]:          # a slot is used by one thread at a time
+            scorers[slot].set_reference(ref)
+            have_ref[slot] = True
         dec, size = codec(q)
         dec = np.ascontiguousarray(dec, dtype=np.uint8)
         if dec.shape != ref.shape:
@@ -148,7 +156,8 @@ def search_speculative_hip(scorers, ref_rgb: np.ndarray,
         def batch(qs):
             return list(pool.map(one, list(enumerate(qs))))
 
-        res, stats = find_target_quality_speculative(batch, score_tgt, tolerance, max_pass, fan)
+        res, stats = find_target_quality_speculative(batch, score_tgt, tolerance, max_pass, fan,
+                                                     min(int(first_wave_fanout), fan))
     res.last_avif_size = sizes.get(res.buf_q, 0)
     return res, stats, sizes
 

@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
         for (uint32_t fan : {1u, 2u, 5u, (uint32_t)OAVIF_TQ_MAX_FANOUT}) {
             Table t2 = t;
             t2.calls = 0;
-            oavif_tq_spec_options so = {fan};
+            oavif_tq_spec_options so = {fan, (uint32_t)(iter % 2 ? 1 : 0)};  // every other search: the first wave alone
             oavif_tq_result r2;
             oavif_tq_spec_stats st;
             std::memset(&r2, 0xCD, sizeof r2);
@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
         CHECK(oavif_tq_find_target_quality(nullptr, table_probe, &t, &r) != 0);
         CHECK(oavif_tq_find_target_quality(&o, nullptr, &t, &r) != 0);
         CHECK(oavif_tq_find_target_quality(&o, table_probe, &t, nullptr) != 0);
-        oavif_tq_spec_options so = {0};
+        oavif_tq_spec_options so = {0, 0};
         oavif_tq_spec_stats st;
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
         so.max_fanout = OAVIF_TQ_MAX_FANOUT + 1;

@@ -190,7 +190,7 @@ def test_cpp_matches_restatement_on_arbitrary_tables(tq, scores, tgt, max_pass):
 
 
 # ---- speculative probe fan-out (include/oavif_tq.h): same result as the sequential search -----
-def run_speculative(tq, fn, fanout, **kw):
+def run_speculative(tq, fn, fanout, first_wave=0, **kw):
     """The speculative search against the restatement of tq.zig, plus the wave invariants."""
     waves = []
 
@@ -198,7 +198,9 @@ def run_speculative(tq, fn, fanout, **kw):
         waves.append(list(qs))
         return [fn(q) for q in qs]
 
-    res, stats = tq.find_target_quality_speculative(batch, max_fanout=fanout, **kw)
+    res, stats = tq.find_target_quality_speculative(batch, max_fanout=fanout, first_wave_fanout=first_wave, **kw)
+    if first_wave and waves:
+        assert len(waves[0]) <= first_wave
     ref = tq_oracle.find_target_quality(fn, **kw)
     assert (res.q, res.num_pass, res.buf_q) == (ref.q, ref.num_pass, ref.buf_q)
     assert res.score == ref.score and res.history == ref.history
@@ -232,6 +234,7 @@ def test_speculative_hand_trace(tq, fanout):
        max_pass=st.integers(1, 12), fanout=st.integers(1, 16))
 def test_speculative_matches_sequential_on_random_curves(tq, fn, tgt, tol, max_pass, fanout):
     run_speculative(tq, fn, fanout, score_tgt=tgt, tolerance=tol, max_pass=max_pass)
+    run_speculative(tq, fn, fanout, first_wave=1 + (max_pass % fanout), score_tgt=tgt, tolerance=tol, max_pass=max_pass)
 
 
 @settings(max_examples=int(__import__('os').environ.get('TQ_EXAMPLES', 200)), deadline=None,
@@ -257,6 +260,21 @@ def test_speculative_errors(tq):
     for fan in (0, 17):
         with pytest.raises(Ssimu2Error):
             tq.find_target_quality_speculative(lambda qs: [50.0] * len(qs), max_fanout=fan)
+    with pytest.raises(Ssimu2Error):
+        tq.find_target_quality_speculative(lambda qs: [50.0] * len(qs), max_fanout=4, first_wave_fanout=5)
+
+
+def test_first_wave_alone_makes_a_one_pass_search_cost_one_probe(tq):
+    """first_wave_fanout = 1: a search that ends on the model's guess issues exactly one probe
+    (what the sequential search does), a longer one still saves waves from the second wave on."""
+    on_target = lambda q: 80.3                                    # noqa: E731  (inside the tolerance at once)
+    res, stats = run_speculative(tq, on_target, 8, first_wave=1)
+    assert (res.num_pass, stats.waves, stats.probes_issued) == (1, 1, 1)
+    res, stats = run_speculative(tq, on_target, 8)
+    assert stats.probes_issued > 1                                # the default first wave speculates
+    table = {65: 84.3, 55: 77.1, 59: 79.2}                        # SURVEY 8a hand trace: three passes
+    res, stats = run_speculative(tq, lambda q: table.get(q, 60.0 + q / 5.0), 16, first_wave=1)
+    assert res.num_pass == 3 and stats.waves <= 3 and stats.probes_issued > 3
 
 
 def test_speculation_saves_waves_on_typical_curves(tq):
