@@ -532,9 +532,10 @@ def main() -> int:
                         c_.close()
                 out["search_end_to_end_4k"] = {
                     "fanout": fan, "encoder_threads": 1, "cases": cases,
-                    "note": "Pillow libavif/aom speed 9 stands in for oavif's encoder; speculative "
-                            "time includes uploading the reference to every context; a search that "
-                            "ends on its first pass only pays for the extra probes"}
+                    "note": "Pillow libavif/aom speed 9 stands in for oavif's encoder; the first wave of the "
+                            "speculative search is the model's guess alone (first_wave_fanout = 1), so a "
+                            "search that ends on its first pass issues one probe like the sequential one; "
+                            "speculation (and the reference upload to further contexts) starts with wave 2"}
             except Exception as e:
                 out["search_end_to_end_4k"] = {"error": str(e)}
 
