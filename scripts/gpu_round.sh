@@ -1,6 +1,6 @@
 #!/bin/bash
-# One recorded GPU-box round: smoke, GPU tests, bench, rocprof kernel stats, PMC counters, VALU
-# microbenchmark, counters.json.   Usage (on the box, repo root): scripts/gpu_round.sh TAG
+# One recorded GPU-box round: smoke, GPU tests, rocprof kernel stats, PMC counters, VALU
+# microbenchmark, counters.json, and last the bench (so that its counter-derived fields are this build's).   Usage (on the box, repo root): scripts/gpu_round.sh TAG
 # Outputs in gpurun_out/TAG/; the summaries to keep are then copied into profiles/ by hand
 # (kernel_stats.csv -> profiles/TAG_kernel_stats.csv, pmc_summary.txt, counters.json, bench.json).
 TAG=${1:-r02}
@@ -11,8 +11,6 @@ python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $
 tail -2 $OUT/smoke.log
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -4 $OUT/pytest_gpu.log
-timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations with the scores of one stream never overlapping (two streams stretch them)
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 512 --warmup 64 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
@@ -26,5 +24,12 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_calib -- $GRAFT_REPO_ROOT/scripts/ubench/fetch_calib > $OUT/pmc_calib.log 2>&1; echo "pmc calib rc=$?"
 cd $GRAFT_REPO_ROOT
 python3 scripts/pmc_summary.py $OUT/pmc_calib/ > $OUT/pmc_calib_summary.txt; rm -rf $OUT/pmc_calib
-python3 scripts/make_counters_json.py $OUT/pmc_summary.txt $OUT/valu_rate.txt > $OUT/counters.json
+# the counter files under the names they are committed under, so that bench.py (which reads
+# profiles/counters.json and checks its source hash) runs LAST, on counters of these very sources
+cp $OUT/pmc_summary.txt profiles/${TAG}_pmc_summary.txt
+cp $OUT/valu_rate.txt profiles/${TAG}_valu_rate.txt
+python3 scripts/make_counters_json.py profiles/${TAG}_pmc_summary.txt profiles/${TAG}_valu_rate.txt > $OUT/counters.json
+cp $OUT/counters.json profiles/counters.json
 cat $OUT/counters.json | head -12
+timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+cat $OUT/bench.json
