@@ -22,10 +22,12 @@
 //              a pass, {x, xx} of the reference), so the shared inputs are fetched once.  Each
 //              wave stages its 20 rows 64 columns at a time through wave-private LDS with coalesced
 //              16-byte loads and stores (see "Staging" below); products are formed on the way in,
-//              rounded to fp32 first as published.  8 VALU instructions per step instead of 15.
+//              rounded to fp32 first as published.  7 VALU instructions per step (8 for a product
+//              plane) instead of 15.
 //   k_rg_v     vertical pass + maps.  lane = image column (coalesced rows), the three sections in
 //              the lane; batches of ten rows, so that the left-hand inputs of a batch are the
-//              right-hand ones of the previous batch; loads two batches ahead.  The blurred
+//              right-hand ones of the previous batch; loads three batches ahead, streaming
+//              (nontemporal: every plane is read once per pass).  The blurred
 //              rows go to a double-buffered LDS tile, where five more waves of the workgroup
 //              turn them -- with the cached reference planes -- into the SSIM / edge-difference
 //              sums (the expressions of k_march): the nine per-pass planes never reach HBM after
