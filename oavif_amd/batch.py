@@ -377,9 +377,12 @@ def main(argv=None) -> int:
     # Host placement first -- before torch is imported, before any GPU call, before a thread
     # exists: every thread started later (encoder workers, the HIP runtime's) inherits the mask.
     from . import hostinfo
-    core_sets = hostinfo.rank_core_sets(local_world, gpu_cpulists=hostinfo.gpu_local_cpulists() or None,
-                                        quota=hostinfo.cgroup_cpu_quota())
-    if not args.no_pin and world > 1:
+    core_sets = hostinfo.node_core_sets(local_world)
+    # one rank alone is pinned too when the cgroup grants fewer CPUs than the affinity mask holds:
+    # a quota is enforced by throttling, and threads that float over the whole host hit it
+    quota = hostinfo.cgroup_cpu_quota()
+    pinned = not args.no_pin and (world > 1 or (quota is not None and quota < len(hostinfo.allowed_cpus())))
+    if pinned:
         hostinfo.pin_rank(local_rank, local_world)
 
     import torch
@@ -442,8 +445,7 @@ def main(argv=None) -> int:
     if rank == 0:
         write_csv(args.output_csv, results)
         print(summarize(results, wall, world))
-        pinned = "" if (not args.no_pin and world > 1) else " (not pinned)"
-        print(f"Host cores per rank{pinned}: " + "; ".join(
+        print(f"Host cores per rank{'' if pinned else ' (not pinned)'}: " + "; ".join(
             f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
         print(f"Worker threads per rank: {args.workers}; dealing: largest file first")
         print("Note: the stand-in codec (Pillow's libavif) writes 8-bit AVIF where oavif defaults to 10-bit "

@@ -153,8 +153,12 @@ inline uint8_t paeth(int a, int b, int c) {
     return (uint8_t)(pa <= pb && pa <= pc ? a : (pb <= pc ? b : c));
 }
 
-// undo the filter of one row in place; `prev` = the unfiltered row above (zeros for a pass's first row)
-int unfilter(int ftype, uint8_t* row, const uint8_t* prev, size_t n, size_t bpp) {
+// undo the filter of one row in place; `prev` = the unfiltered row above (zeros for a pass's first
+// row).  BPP as a compile-time constant for the common pixel sizes: the left / upper-left
+// neighbours then live in registers (the generic loop re-reads them through memory).
+template <size_t BPP>
+int unfilter_bpp(int ftype, uint8_t* row, const uint8_t* prev, size_t n, size_t bpp_dyn) {
+    const size_t bpp = BPP ? BPP : bpp_dyn;
     switch (ftype) {
         case 0: return 0;
         case 1:
@@ -163,19 +167,27 @@ int unfilter(int ftype, uint8_t* row, const uint8_t* prev, size_t n, size_t bpp)
         case 2:
             for (size_t i = 0; i < n; ++i) row[i] = (uint8_t)(row[i] + prev[i]);
             return 0;
-        case 3:
-            for (size_t i = 0; i < n; ++i) {
-                const int a = i >= bpp ? row[i - bpp] : 0;
-                row[i] = (uint8_t)(row[i] + ((a + prev[i]) >> 1));
-            }
+        case 3: {
+            const size_t head = bpp < n ? bpp : n;
+            for (size_t i = 0; i < head; ++i) row[i] = (uint8_t)(row[i] + (prev[i] >> 1));
+            for (size_t i = head; i < n; ++i) row[i] = (uint8_t)(row[i] + ((row[i - bpp] + prev[i]) >> 1));
             return 0;
-        case 4:
-            for (size_t i = 0; i < n; ++i) {
-                const int a = i >= bpp ? row[i - bpp] : 0, c = i >= bpp ? prev[i - bpp] : 0;
-                row[i] = (uint8_t)(row[i] + paeth(a, prev[i], c));
-            }
+        }
+        case 4: {
+            const size_t head = bpp < n ? bpp : n;
+            for (size_t i = 0; i < head; ++i) row[i] = (uint8_t)(row[i] + prev[i]);  // paeth(0, b, 0) = b
+            for (size_t i = head; i < n; ++i) row[i] = (uint8_t)(row[i] + paeth(row[i - bpp], prev[i], prev[i - bpp]));
             return 0;
+        }
         default: return -1;
+    }
+}
+int unfilter(int ftype, uint8_t* row, const uint8_t* prev, size_t n, size_t bpp) {
+    switch (bpp) {
+        case 1: return unfilter_bpp<1>(ftype, row, prev, n, bpp);
+        case 3: return unfilter_bpp<3>(ftype, row, prev, n, bpp);
+        case 4: return unfilter_bpp<4>(ftype, row, prev, n, bpp);
+        default: return unfilter_bpp<0>(ftype, row, prev, n, bpp);
     }
 }
 
@@ -258,23 +270,17 @@ const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, 
 
 extern "C" {
 
-int oavif_png_info_from_memory(const uint8_t* png_bytes, size_t len, oavif_png_info* out) {
-    if (!png_bytes || !out) return OAVIF_PNG_ERR_ARG;
-    memset(out, 0, sizeof *out);
-    Png png;
-    int rc;
-    try {
-        rc = parse(png_bytes, len, png);
-    } catch (...) {
-        return OAVIF_PNG_ERR_OOM;
-    }
-    if (rc) return rc;
+}  // extern "C"
+
+namespace {
+// the output geometry of a parsed file (+ its decompressed profile)
+int describe(const Png& png, std::vector<uint8_t>& icc, oavif_png_info* out) {
     const uint64_t px = (uint64_t)png.w * png.h;
     const uint64_t bytes = px * png.out_channels() * (png.hbd() ? 2u : 1u);
     if (px > (1ull << 40) || bytes / png.out_channels() / (png.hbd() ? 2u : 1u) != px || bytes > (uint64_t)SIZE_MAX / 2)
         return OAVIF_PNG_ERR_SIZE;
-    std::vector<uint8_t> icc;
-    if ((rc = inflate_icc(png, icc))) return rc;
+    const int rc = inflate_icc(png, icc);
+    if (rc) return rc;
     out->width = png.w;
     out->height = png.h;
     out->channels = png.out_channels();
@@ -286,23 +292,38 @@ int oavif_png_info_from_memory(const uint8_t* png_bytes, size_t len, oavif_png_i
     out->interlaced = (uint32_t)png.interlace;
     return OAVIF_PNG_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int oavif_png_info_from_memory(const uint8_t* png_bytes, size_t len, oavif_png_info* out) {
+    if (!png_bytes || !out) return OAVIF_PNG_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    try {
+        Png png;
+        const int rc = parse(png_bytes, len, png);
+        if (rc) return rc;
+        std::vector<uint8_t> icc;
+        return describe(png, icc, out);
+    } catch (...) {
+        return OAVIF_PNG_ERR_OOM;
+    }
+}
 
 int oavif_png_decode(const uint8_t* png_bytes, size_t len, uint8_t* out_pixels, size_t out_cap, uint8_t* out_icc,
                      size_t icc_cap) {
     if (!png_bytes || !out_pixels) return OAVIF_PNG_ERR_ARG;
-    oavif_png_info info;
-    int rc = oavif_png_info_from_memory(png_bytes, len, &info);
-    if (rc) return rc;
-    if (out_cap < info.data_bytes || (info.icc_bytes && out_icc && icc_cap < info.icc_bytes)) return OAVIF_PNG_ERR_SIZE;
-    if (info.hbd && (reinterpret_cast<uintptr_t>(out_pixels) & 1u)) return OAVIF_PNG_ERR_ARG;  // u16 output
     try {
         Png png;
-        if ((rc = parse(png_bytes, len, png))) return rc;
-        if (out_icc && info.icc_bytes) {
-            std::vector<uint8_t> icc;
-            if ((rc = inflate_icc(png, icc))) return rc;
-            memcpy(out_icc, icc.data(), icc.size());
-        }
+        int rc = parse(png_bytes, len, png);  // one walk over the chunks (and their CRCs)
+        if (rc) return rc;
+        oavif_png_info info;
+        memset(&info, 0, sizeof info);
+        std::vector<uint8_t> icc;
+        if ((rc = describe(png, icc, &info))) return rc;
+        if (out_cap < info.data_bytes || (info.icc_bytes && out_icc && icc_cap < info.icc_bytes)) return OAVIF_PNG_ERR_SIZE;
+        if (info.hbd && (reinterpret_cast<uintptr_t>(out_pixels) & 1u)) return OAVIF_PNG_ERR_ARG;  // u16 output
+        if (out_icc && info.icc_bytes) memcpy(out_icc, icc.data(), icc.size());
         // filtered scanlines of every pass: 1 filter byte + the row
         size_t need = 0;
         uint32_t pw[7], ph[7];
@@ -354,8 +375,12 @@ int oavif_png_decode(const uint8_t* png_bytes, size_t len, uint8_t* out_pixels, 
                 uint8_t* row = raw.data() + off + 1;
                 if (unfilter(raw[off], row, prev, rb, bpp)) return OAVIF_PNG_ERR_DECODE;
                 const uint32_t y = a.y0 + j * a.dy;
-                for (uint32_t i = 0; i < pw[k]; ++i)
-                    if (!ex.put(row, i, a.x0 + i * a.dx, y)) return OAVIF_PNG_ERR_DECODE;
+                if (!png.interlace && png.depth == 8 && (png.ctype == 2 || png.ctype == 6)) {
+                    memcpy(out_pixels + (size_t)y * rb, row, rb);  // RGB8 / RGBA8 rows go out as they are
+                } else {
+                    for (uint32_t i = 0; i < pw[k]; ++i)
+                        if (!ex.put(row, i, a.x0 + i * a.dx, y)) return OAVIF_PNG_ERR_DECODE;
+                }
                 prev = row;
                 off += 1 + rb;
             }

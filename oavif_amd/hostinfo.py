@@ -94,9 +94,53 @@ def sibling_order(cpus: Sequence[int], sysfs: str = "/sys") -> List[int]:
     return sorted(cpus, key=key)
 
 
+def core_groups(cpus: Sequence[int], sysfs: str = "/sys") -> Dict[int, int]:
+    """cpu id -> id of its physical core (the lowest hardware-thread id of the core); a cpu
+    without sysfs topology is its own core."""
+    out: Dict[int, int] = {}
+    for c in cpus:
+        try:
+            out[c] = min(parse_cpulist(open(os.path.join(
+                sysfs, f"devices/system/cpu/cpu{c}/topology/thread_siblings_list")).read()))
+        except Exception:
+            out[c] = c
+    return out
+
+
+def one_thread_per_core_first(cpus: Sequence[int], groups: Optional[Dict[int, int]] = None) -> List[int]:
+    """`cpus` reordered: the first hardware thread of every physical core, then the second ones, ...
+    A slice that a cgroup quota cuts short then keeps whole cores busy instead of pairs of SMT
+    siblings (measured on the GPU box, 16-CPU quota, 16 encoder threads: 46.8 images/s on 16
+    cores against 40.1 on 8 cores x 2 threads -- and 22 unpinned, see pin_rank)."""
+    groups = groups if groups is not None else core_groups(cpus)
+    seen: Dict[int, int] = {}
+    ranked = []
+    for c in cpus:
+        g = groups.get(c, c)
+        k = seen.get(g, 0)
+        seen[g] = k + 1
+        ranked.append((k, c))
+    return [c for _, c in sorted(ranked, key=lambda t: t[0])]   # stable: keeps the order inside a round
+
+
+def visible_gpu_indices() -> Optional[List[int]]:
+    """Indices (in the node's enumeration) of the GPUs the runtime will show this process, from
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they are plain numbers;
+    None = no restriction known."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                return [int(t) for t in v.split(",") if t.strip() != ""]
+            except ValueError:
+                return None
+    return None
+
+
 def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
                    gpu_cpulists: Optional[Sequence[Sequence[int]]] = None,
-                   quota: Optional[float] = None) -> List[List[int]]:
+                   quota: Optional[float] = None,
+                   core_of: Optional[Dict[int, int]] = None) -> List[List[int]]:
     """Disjoint host core sets for the `local_world` ranks of one node, rank r <-> GPU r.
 
     Ranks whose GPUs share a NUMA node split that node's allowed cores into contiguous slices
@@ -128,14 +172,35 @@ def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
             sets[r] = list(near[lo: lo + per]) or [near[-1]]
     if quota is not None:
         share = max(1, int(quota / local_world + 0.5))
-        sets = [s[:share] for s in sets]
+        sets = [one_thread_per_core_first(s, core_of)[:share] if len(s) > share else s for s in sets]
     return sets
+
+
+def node_core_sets(local_world: int) -> List[List[int]]:
+    """rank_core_sets for this node as it is: sysfs topology, cgroup quota, and -- when the job
+    sees only some of the node's GPUs (a shared host: *_VISIBLE_DEVICES) -- only the slices those
+    GPUs would get if every GPU of the node ran a rank, so that tenants of one host pin themselves
+    to different cores."""
+    cpus = sibling_order(allowed_cpus())
+    gpus = gpu_local_cpulists() or None
+    quota = cgroup_cpu_quota()
+    vis = visible_gpu_indices()
+    if gpus and vis and len(vis) < len(gpus) and all(0 <= v < len(gpus) for v in vis):
+        node = rank_core_sets(len(gpus), cpus=cpus, gpu_cpulists=gpus)
+        mine = [c for v in vis for c in node[v]]
+        if mine:
+            return rank_core_sets(local_world, cpus=mine, quota=quota)
+    return rank_core_sets(local_world, cpus=cpus, gpu_cpulists=gpus, quota=quota)
 
 
 def pin_rank(local_rank: int, local_world: int) -> List[int]:
     """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
-    before the first GPU call and before any thread pool exists.  Returns the set."""
-    sets = rank_core_sets(local_world, gpu_cpulists=gpu_local_cpulists() or None, quota=cgroup_cpu_quota())
+    before the first GPU call and before any thread pool exists.  Returns the set.
+
+    Worth doing for a single rank too when a cgroup quota is far below the affinity mask: 16
+    encoder threads floating over the 256 CPUs of the GPU host under a 16-CPU quota ran 22 images/s,
+    pinned to 16 cores 45 (the quota is enforced by throttling, which a pinned job never hits)."""
+    sets = node_core_sets(local_world)
     mine = sets[local_rank % len(sets)]
     try:
         os.sched_setaffinity(0, mine)

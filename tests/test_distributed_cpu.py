@@ -84,13 +84,30 @@ def test_rank_core_sets_are_disjoint_near_their_gpu_and_within_the_quota():
     sets = hostinfo.rank_core_sets(8, cpus=list(range(256)), gpu_cpulists=[s0] * 4 + [s1] * 4)
     assert all(set(sets[r]) <= set(s0) for r in range(4)) and all(set(sets[r]) <= set(s1) for r in range(4, 8))
     assert len(set(sum(sets, []))) == sum(len(s) for s in sets) == 256
-    # a cgroup that grants 16 CPUs to a job of two ranks: eight threads each, still disjoint
+    # a cgroup that grants 16 CPUs to a job of two ranks: eight threads each, still disjoint --
+    # and eight different physical cores each, not four cores and their SMT siblings
+    sib = [x for c in range(128) for x in (c, c + 128)]            # sibling_order of such a host
+    core_of = {c: c % 128 for c in range(256)}
+    sets = hostinfo.rank_core_sets(2, cpus=sib, quota=16.0, core_of=core_of)
+    assert sets == [list(range(0, 8)), list(range(64, 72))]
+    assert hostinfo.one_thread_per_core_first([0, 128, 1, 129, 2], core_of) == [0, 1, 2, 128, 129]
     sets = hostinfo.rank_core_sets(2, cpus=list(range(256)), quota=16.0)
     assert [len(s) for s in sets] == [8, 8] and not set(sets[0]) & set(sets[1])
     assert hostinfo.rank_core_sets(3, cpus=[4, 5]) == [[4], [5], [5]]      # more ranks than cores: still a set each
     assert hostinfo.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert hostinfo.format_cpus([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
     assert 1 <= hostinfo.usable_cores() <= 32
+    # a tenant that sees GPU 5 of eight takes the cores GPU 5 would get on a fully used node
+    import os
+    old = os.environ.get("ROCR_VISIBLE_DEVICES")
+    os.environ["ROCR_VISIBLE_DEVICES"] = "5"
+    try:
+        assert hostinfo.visible_gpu_indices() == [5]
+    finally:
+        if old is None:
+            del os.environ["ROCR_VISIBLE_DEVICES"]
+        else:
+            os.environ["ROCR_VISIBLE_DEVICES"] = old
 
 
 @pytest.fixture(scope="module")
