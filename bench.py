@@ -572,7 +572,12 @@ def main() -> int:
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ssimu2_oracle as orc
+            from oavif_amd import hostinfo
             orc.build()
+            # Pin before the first OpenMP region creates its threads: under a cgroup quota far below
+            # the affinity mask (16 of 256 CPUs on the pool's boxes) unpinned threads are throttled,
+            # and the CPU figure comes out a third too low (35-37 vs 53 MP/s, scripts/cpu_oracle_rate.py)
+            pinned = hostinfo.format_cpus(hostinfo.pin_rank(0, 1))
             cores = orc.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores())
             orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)  # spin up
             tc = time.perf_counter()
@@ -588,7 +593,7 @@ def main() -> int:
             orc.compute_ssimu2(crop_r, crop_d, orc.BLUR_FIR, omp=False)
             dt1 = time.perf_counter() - t1
             out["cpu_baseline"] = {
-                "value": round(mp / dt, 3), "unit": "MP/s", "cores": cores, "kind": "port",
+                "value": round(mp / dt, 3), "unit": "MP/s", "cores": cores, "pinned_to_cpus": pinned, "kind": "port",
                 "sample": f"{reps} x the same {w}x{h} pair, oracle/ssimu2_oracle.c (FIR, "
                           f"OpenMP, {cores} threads, build {orc.omp_build_name()}); not the "
                           f"reference's Zig+fssimu2 (unbuildable here)",
