@@ -110,6 +110,36 @@ def test_rank_core_sets_are_disjoint_near_their_gpu_and_within_the_quota():
             os.environ["ROCR_VISIBLE_DEVICES"] = old
 
 
+def test_gpu_numa_topology_is_read_from_sysfs(tmp_path):
+    """gpu_local_cpulists: AMD display / accelerator PCI functions only, in PCI address order;
+    sibling_order / core_groups from cpuN/topology/thread_siblings_list."""
+    from oavif_amd import hostinfo
+    devs = tmp_path / "bus" / "pci" / "devices"
+    spec = [("0000:05:00.0", "0x1002", "0x120000", "0-3,8-11"),      # MI-class accelerator, socket 0
+            ("0000:85:00.0", "0x1002", "0x120000", "4-7,12-15"),     # ... socket 1
+            ("0000:03:00.0", "0x1a03", "0x030000", "0-3,8-11"),      # the BMC's VGA: not AMD
+            ("0000:05:00.1", "0x1002", "0x040300", "0-3,8-11"),      # an AMD audio function: not a GPU
+            ("0000:45:00.0", "0x1002", "0x038000", "0-3,8-11")]      # display controller, socket 0
+    for addr, vendor, cls, cpus in spec:
+        d = devs / addr
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    got = hostinfo.gpu_local_cpulists(str(tmp_path))
+    assert got == [[0, 1, 2, 3, 8, 9, 10, 11], [0, 1, 2, 3, 8, 9, 10, 11], [4, 5, 6, 7, 12, 13, 14, 15]]
+    for c in range(16):
+        t = tmp_path / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        t.mkdir(parents=True)
+        (t / "thread_siblings_list").write_text(f"{c % 8},{c % 8 + 8}\n")
+    assert hostinfo.sibling_order(range(16), str(tmp_path)) == [0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15]
+    assert hostinfo.core_groups([3, 11, 12], str(tmp_path)) == {3: 3, 11: 3, 12: 4}
+    sets = hostinfo.rank_core_sets(3, cpus=hostinfo.sibling_order(range(16), str(tmp_path)), gpu_cpulists=got,
+                                   quota=6.0, core_of=hostinfo.core_groups(range(16), str(tmp_path)))
+    # GPUs 0 and 1 share socket 0 (cores 0-3 + siblings): two cores each, one thread per core under the quota
+    assert sets == [[0, 1], [2, 3], [4, 5]]
+
+
 @pytest.fixture(scope="module")
 def varied_dir(tmp_path_factory, hip_lib):
     from PIL import Image
