@@ -354,6 +354,10 @@ def parse_cli(argv=None):
                          "default: the rank's share of the usable host cores")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the rank to its slice of the node's host cores")
+    ap.add_argument("--procs-per-gpu", type=int, default=int(os.environ.get("OAVIF_PROCS_PER_GPU", "1") or 1),
+                    help="ranks that share one GPU (launch nproc-per-node = GPUs x this): the CPU codec is the "
+                         "cost of a pass and several processes per GPU use the host's cores better than one "
+                         "process with as many threads; the gather of such a job runs over gloo")
     ap.add_argument("--out-dir", default="temp_avif_output")
     args = ap.parse_args(argv)
     if len(args.paths) == 2:
@@ -377,23 +381,27 @@ def main(argv=None) -> int:
     # Host placement first -- before torch is imported, before any GPU call, before a thread
     # exists: every thread started later (encoder workers, the HIP runtime's) inherits the mask.
     from . import hostinfo
-    core_sets = hostinfo.node_core_sets(local_world)
+    ppg = max(1, int(args.procs_per_gpu))
+    core_sets = hostinfo.node_core_sets(local_world, procs_per_gpu=ppg)
     # one rank alone is pinned too when the cgroup grants fewer CPUs than the affinity mask holds:
     # a quota is enforced by throttling, and threads that float over the whole host hit it
     quota = hostinfo.cgroup_cpu_quota()
     pinned = not args.no_pin and (world > 1 or (quota is not None and quota < len(hostinfo.allowed_cpus())))
     if pinned:
-        hostinfo.pin_rank(local_rank, local_world)
+        hostinfo.pin_rank(local_rank, local_world, procs_per_gpu=ppg)
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         print("oavif_amd.batch: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
         return 3
-    # One process per GPU over RCCL (backend "nccl").  OAVIF_BENCH_BACKEND=gloo is the rehearsal
-    # mode bench.py also has, for boxes with fewer GPUs than ranks: ranks share devices
-    # (local_rank modulo the device count) and the one gather runs on CPU tensors.
-    backend = os.environ.get("OAVIF_BENCH_BACKEND", "nccl")
+    # One process per GPU over RCCL (backend "nccl").  With --procs-per-gpu K > 1, K consecutive
+    # local ranks share a GPU (rank r -> GPU r // K) and the one gather of 64-byte records runs
+    # over gloo on CPU tensors: RCCL does not place two ranks on one device.  OAVIF_BENCH_BACKEND=gloo
+    # is the rehearsal mode bench.py also has, for boxes with fewer GPUs than ranks (local_rank
+    # modulo the device count).
+    backend = os.environ.get("OAVIF_BENCH_BACKEND", "gloo" if ppg > 1 else "nccl")
+    local_rank = local_rank // ppg
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -447,7 +455,7 @@ def main(argv=None) -> int:
         print(summarize(results, wall, world))
         print(f"Host cores per rank{'' if pinned else ' (not pinned)'}: " + "; ".join(
             f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
-        print(f"Worker threads per rank: {args.workers}; dealing: largest file first")
+        print(f"Worker threads per rank: {args.workers}; ranks per GPU: {ppg}; dealing: largest file first")
         print("Note: the stand-in codec (Pillow's libavif) writes 8-bit AVIF where oavif defaults to 10-bit "
               "(parse_args.zig:56): byte sizes and chosen quantizers are not those of the reference's measure.py run")
         print(f"\nResults written to {args.output_csv}")

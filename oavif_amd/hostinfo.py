@@ -176,31 +176,35 @@ def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
     return sets
 
 
-def node_core_sets(local_world: int) -> List[List[int]]:
+def node_core_sets(local_world: int, procs_per_gpu: int = 1) -> List[List[int]]:
     """rank_core_sets for this node as it is: sysfs topology, cgroup quota, and -- when the job
     sees only some of the node's GPUs (a shared host: *_VISIBLE_DEVICES) -- only the slices those
     GPUs would get if every GPU of the node ran a rank, so that tenants of one host pin themselves
-    to different cores."""
+    to different cores.  `procs_per_gpu` consecutive local ranks share a GPU (rank r -> GPU
+    r // procs_per_gpu) and split that GPU's cores."""
     cpus = sibling_order(allowed_cpus())
     gpus = gpu_local_cpulists() or None
+    if gpus and procs_per_gpu > 1:
+        gpus = [g for g in gpus for _ in range(procs_per_gpu)]
     quota = cgroup_cpu_quota()
     vis = visible_gpu_indices()
-    if gpus and vis and len(vis) < len(gpus) and all(0 <= v < len(gpus) for v in vis):
-        node = rank_core_sets(len(gpus), cpus=cpus, gpu_cpulists=gpus)
+    ngpu = len(gpus) // max(1, procs_per_gpu) if gpus else 0
+    if gpus and vis and len(vis) < ngpu and all(0 <= v < ngpu for v in vis):
+        node = rank_core_sets(ngpu, cpus=cpus, gpu_cpulists=gpus[::max(1, procs_per_gpu)])
         mine = [c for v in vis for c in node[v]]
         if mine:
             return rank_core_sets(local_world, cpus=mine, quota=quota)
     return rank_core_sets(local_world, cpus=cpus, gpu_cpulists=gpus, quota=quota)
 
 
-def pin_rank(local_rank: int, local_world: int) -> List[int]:
+def pin_rank(local_rank: int, local_world: int, procs_per_gpu: int = 1) -> List[int]:
     """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
     before the first GPU call and before any thread pool exists.  Returns the set.
 
     Worth doing for a single rank too when a cgroup quota is far below the affinity mask: 16
     encoder threads floating over the 256 CPUs of the GPU host under a 16-CPU quota ran 22 images/s,
     pinned to 16 cores 45 (the quota is enforced by throttling, which a pinned job never hits)."""
-    sets = node_core_sets(local_world)
+    sets = node_core_sets(local_world, procs_per_gpu)
     mine = sets[local_rank % len(sets)]
     try:
         os.sched_setaffinity(0, mine)

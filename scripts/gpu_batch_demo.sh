@@ -16,13 +16,16 @@ for w in 1 16; do
 done
 echo "== workers=default, published-recursion blur mode (OAVIF_SSIMU2_BLUR=recursive)"
 OAVIF_SSIMU2_BLUR=recursive python -m oavif_amd.batch $D/imgs $D/out_r.csv --out-dir $D/or 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average passes|Worker threads"
-echo "== two ranks (rehearsal: both on GPU 0, the gather over gloo), pinned to disjoint host cores, largest file first"
-OAVIF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-  -m oavif_amd.batch $D/imgs $D/out_2r.csv --out-dir $D/o2r 2>/dev/null | grep -E "Images:|Ranks|Total wall|Throughput|Host cores|Worker threads"
+for k in 2 4; do
+echo "== --procs-per-gpu $k: $k ranks on GPU 0 (the gather over gloo), pinned to disjoint host cores, largest file first"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node $k --master-addr 127.0.0.1 --master-port 2953$k \
+  -m oavif_amd.batch $D/imgs $D/out_${k}r.csv --out-dir $D/o${k}r --procs-per-gpu $k 2>/dev/null | grep -E "Images:|Ranks|Total wall|Throughput|Host cores|Worker threads"
+done
 python - <<PY
 import csv
 a = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_1.csv"))]
 b = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_16.csv"))]
 c = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_2r.csv"))]
-print("identical results (1 worker, 16 workers, 2 ranks):", a == b == c)
+d = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_4r.csv"))]
+print("identical results (1 worker, 16 workers, 2 ranks, 4 ranks):", a == b == c == d)
 PY

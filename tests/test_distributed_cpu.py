@@ -94,6 +94,10 @@ def test_rank_core_sets_are_disjoint_near_their_gpu_and_within_the_quota():
     sets = hostinfo.rank_core_sets(2, cpus=list(range(256)), quota=16.0)
     assert [len(s) for s in sets] == [8, 8] and not set(sets[0]) & set(sets[1])
     assert hostinfo.rank_core_sets(3, cpus=[4, 5]) == [[4], [5], [5]]      # more ranks than cores: still a set each
+    # --procs-per-gpu 2 on that node: sixteen ranks, rank r on GPU r // 2, each GPU's slice split in two
+    sets = hostinfo.rank_core_sets(16, cpus=list(range(256)), gpu_cpulists=[g for g in [s0] * 4 + [s1] * 4 for _ in range(2)])
+    assert [len(s) for s in sets] == [16] * 16 and len(set(sum(sets, []))) == 256
+    assert all(set(sets[r]) <= set(s0) for r in range(8)) and all(set(sets[r]) <= set(s1) for r in range(8, 16))
     assert hostinfo.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert hostinfo.format_cpus([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
     assert 1 <= hostinfo.usable_cores() <= 32
