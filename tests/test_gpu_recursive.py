@@ -81,6 +81,27 @@ def test_recursive_score_matches_the_oracles_published_recursion(rscorer, oracle
     assert rscorer.compute_ssimu2(ref, ref) == 100.0
 
 
+def test_recursive_tile_and_batch_boundaries(rscorer, oracle):
+    """Every width from 56 to 140 -- all residues of the 64-column staging tile and of its output
+    ring, one to three tiles per row, with and without a partial last tile and with the row's last
+    four steps in a tile of their own -- at heights around the 20-row wave, the 10-row batch and the
+    4-row padding of the queue: score and 108 averages against the oracle's recursion."""
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for w in range(56, 141):
+        for h in (19, 20, 21, 40, 41):
+            ref = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            dist = np.clip(ref.astype(np.int16) + rng.integers(-20, 21, ref.shape), 0, 255).astype(np.uint8)
+            got = rscorer.compute_ssimu2(ref, dist)
+            avg_g, ns_g = rscorer.last_averages()
+            exp, avg_o, ns_o = oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR, return_averages=True)
+            assert ns_g == ns_o, (w, h)
+            assert np.allclose(avg_g, avg_o, rtol=RTOL_AVG, atol=1e-9), (w, h, np.abs(avg_g - avg_o).max())
+            assert abs(got - exp) <= TOL_SCORE * max(1.0, abs(exp) / 100.0), (w, h, got, exp)
+            worst = max(worst, abs(got - exp))
+    print("recursive boundary sweep: worst |dscore|", worst)
+
+
 def test_recursive_scores_of_the_golden_fixtures(rscorer, golden, anchors):
     """The committed fixtures carry the oracle's published-recursion score (pairs_v1_anchors.json,
     pinned on the CPU by tests/test_oracle.py): the GPU's recursive mode returns it."""
