@@ -84,10 +84,10 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
      SSIMU2_BLUR_RECURSIVE  (the CONSERVATIVE-PARITY mode) the published recursion itself (libjxl
                             FastGaussian: three second-order sections, products rounded to fp32
                             first, horizontal then vertical), operation for operation, planes
-                            bit-identical to the CPU checker's.  0.5 ms per 4K pass against a
+                            bit-identical to the CPU checker's.  0.4 ms per 4K pass against a
                             reference set with ssimu2_set_reference (whose XYB planes, blur(x) and
                             blur(x*x) are then cached, so a pass recurses 9 of the 15 planes),
-                            0.9 ms for a pair score.
+                            0.8 ms for a pair score.
    The two differ by the recursion's own fp32 rounding noise, which grows with the line length:
    median 0.02 points on 384x256 frames, 0.13 at 1080p, 0.47 (max 2.4) at 4K; against the operator
    accumulated in fp64 the FIR form is within 0.0005 at 4K, the recursion about 1 point off.

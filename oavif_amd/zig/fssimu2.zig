@@ -55,7 +55,7 @@ pub var cache_reference: bool = true;
 ///   `.fir`        the THROUGHPUT mode (default; what the benchmarks measure): the fused 9-tap
 ///                 kernels, 0.16 ms per 4K pass;
 ///   `.recursive`  the CONSERVATIVE-PARITY mode: the published recursive Gaussian operation for
-///                 operation (libjxl's order; planes bit-identical to the CPU checker's), 0.5 ms per
+///                 operation (libjxl's order; planes bit-identical to the CPU checker's), 0.4 ms per
 ///                 4K pass with the reference cached -- still 0.3 % of a pass's encode + decode.
 /// The two differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5
 /// at 4K, where a third of the searches then end on another quantizer); which of them fssimu2
