@@ -27,7 +27,8 @@ extern "C" {
    SSIMU2_ERR_INVALID_ARG if that level does not exist. */
 enum { SSIMU2_DEBUG_LIN_REF = 0, SSIMU2_DEBUG_LIN_DIST = 1, SSIMU2_DEBUG_XYB_REF = 2, SSIMU2_DEBUG_REF_BLUR = 3,
        /* SSIMU2_BLUR_RECURSIVE: the FIFTEEN planes (5 * channel + {x, y, xx, yy, xy}) after the
-          horizontal / after both passes, of the scale processed last (`out`: 15 planes) */
+          horizontal / after both passes, of the scale chosen with ssimu2_instr_rg_stop_after_scale
+          (`out`: 15 planes) */
        SSIMU2_DEBUG_RG_H = 4, SSIMU2_DEBUG_RG_V = 5 };
 int ssimu2_debug_download(ssimu2_ctx* ctx, int what, int scale, uint32_t w, uint32_t h, float* out,
                           uint32_t* out_w, uint32_t* out_h);
@@ -73,8 +74,11 @@ int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
    algorithmic bytes of one launch (every plane element read once, written once). */
 int ssimu2_time_blur_stage_rotating(ssimu2_ctx* ctx, const void* const* d_frames, int nframes, uint32_t w,
                                     uint32_t h, int iters, float* out_ms_avg, double* out_bytes_per_launch);
-/* recursive mode: process scales 0..scale only, so that scale's planes stay downloadable
-   (the score of such a run is meaningless); negative = all scales again */
+/* recursive modes: keep the 15 raw planes of `scale` downloadable (SSIMU2_DEBUG_RG_H / _RG_V) --
+   the horizontal-pass planes are copied out of the pass buffer, the vertical-pass planes of the
+   distorted frame, which otherwise exist only in LDS, are recomputed into a debug buffer; the score
+   of such a run is the normal one.  Negative = keep nothing.  (The name is round 2's, when the run
+   stopped after that scale.) */
 int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* ctx, int scale);
 
 #if defined(__GNUC__)

@@ -203,14 +203,16 @@ class Ssimu2:
 
     def set_blur(self, mode: int) -> None:
         """ssimu2_ctx_set_blur: _lib.BLUR_FIR (default, the fused 9-tap kernels) or
-        _lib.BLUR_RECURSIVE (the published recursion, operation for operation; ~9x slower at 4K)."""
+        _lib.BLUR_RECURSIVE (the published recursion, operation for operation: 0.4 ms per 4K pass
+        against a cached reference where the default takes 0.16)."""
         rc = self._L.ssimu2_ctx_set_blur(self._ctx, int(mode))
         if rc != 0:
             self._raise(rc)
 
     def rg_stop_after_scale(self, scale: int) -> None:
-        """Instrumented build: the recursive mode processes scales 0..scale only, so that scale's
-        15 planes stay downloadable (debug_download what = 4 / 5); negative = all scales."""
+        """Instrumented build: the recursive mode keeps the 15 raw planes of `scale` (after the
+        horizontal pass and after both passes) downloadable (debug_download what = 4 / 5);
+        negative = keep nothing.  (The name is round 2's, when the run stopped after that scale.)"""
         self._need_instr()
         rc = self._L.ssimu2_instr_rg_stop_after_scale(self._ctx, int(scale))
         if rc != 0:
