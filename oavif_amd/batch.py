@@ -388,7 +388,9 @@ def main(argv=None) -> int:
     quota = hostinfo.cgroup_cpu_quota()
     pinned = not args.no_pin and (world > 1 or (quota is not None and quota < len(hostinfo.allowed_cpus())))
     if pinned:
-        hostinfo.pin_rank(local_rank, local_world, procs_per_gpu=ppg)
+        mine = hostinfo.pin_rank(local_rank, local_world, procs_per_gpu=ppg)
+        if world == 1:
+            core_sets = [mine]   # one process under a quota: the idlest cores near the GPU, picked just now
 
     import torch
     import torch.distributed as dist

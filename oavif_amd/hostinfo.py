@@ -197,6 +197,60 @@ def node_core_sets(local_world: int, procs_per_gpu: int = 1) -> List[List[int]]:
     return rank_core_sets(local_world, cpus=cpus, gpu_cpulists=gpus, quota=quota)
 
 
+def read_cpu_ticks(path: str = "/proc/stat") -> Dict[int, tuple]:
+    """cpu id -> (busy ticks, total ticks) from /proc/stat ({} when it cannot be read)."""
+    out: Dict[int, tuple] = {}
+    try:
+        for line in open(path):
+            if line.startswith("cpu") and line[3:4].isdigit():
+                f = line.split()
+                v = [int(x) for x in f[1:9]]
+                idle = v[3] + v[4]              # idle + iowait
+                out[int(f[0][3:])] = (sum(v) - idle, sum(v))
+    except Exception:
+        return {}
+    return out
+
+
+def pick_idle_cpus(cpus: Sequence[int], n: int, sample_s: float = 0.1, core_of: Optional[Dict[int, int]] = None,
+                   sampler=read_cpu_ticks, sleep=None) -> List[int]:
+    """The `n` least busy of `cpus` over a short sample of /proc/stat, whole physical cores first
+    (a core counts as busy as its busiest hardware thread).  For a job that shares its host with
+    other tenants: a fixed slice of the host is fine on a node one owns, but on a shared host it may
+    be exactly where somebody else's threads are (measured: the same pinned OpenMP run 61 MP/s on
+    idle cores, 28 MP/s on cores another tenant was using).  Falls back to the first n of
+    one_thread_per_core_first(cpus) when /proc/stat does not help."""
+    import time as _time
+    cpus = list(cpus)
+    order = one_thread_per_core_first(cpus, core_of)
+    if n >= len(cpus):
+        return order
+    a = sampler()
+    (sleep or _time.sleep)(sample_s)
+    b = sampler()
+    if not a or not b or any(c not in a or c not in b for c in cpus):
+        return order[:n]
+    core_of = core_of if core_of is not None else core_groups(cpus)
+    busy = {}
+    for c in cpus:
+        dt = b[c][1] - a[c][1]
+        busy[c] = (b[c][0] - a[c][0]) / dt if dt > 0 else 0.0
+    core_busy: Dict[int, float] = {}
+    for c in cpus:
+        g = core_of.get(c, c)
+        core_busy[g] = max(core_busy.get(g, 0.0), busy[c])
+    rank = {c: i for i, c in enumerate(order)}
+    nth: Dict[int, int] = {}                     # 0 for the first hardware thread of its core seen, 1 for the second, ...
+    seen: Dict[int, int] = {}
+    for c in cpus:
+        g = core_of.get(c, c)
+        nth[c] = seen.get(g, 0)
+        seen[g] = nth[c] + 1
+    # one thread of every core before any second thread; among those the idlest cores; ties in the given order
+    chosen = sorted(cpus, key=lambda c: (nth[c], round(core_busy[core_of.get(c, c)], 2), rank[c]))[:n]
+    return sorted(chosen, key=lambda c: rank[c])
+
+
 def pin_rank(local_rank: int, local_world: int, procs_per_gpu: int = 1) -> List[int]:
     """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
     before the first GPU call and before any thread pool exists.  Returns the set.
@@ -204,8 +258,21 @@ def pin_rank(local_rank: int, local_world: int, procs_per_gpu: int = 1) -> List[
     Worth doing for a single rank too when a cgroup quota is far below the affinity mask: 16
     encoder threads floating over the 256 CPUs of the GPU host under a 16-CPU quota ran 22 images/s,
     pinned to 16 cores 45 (the quota is enforced by throttling, which a pinned job never hits)."""
-    sets = node_core_sets(local_world, procs_per_gpu)
-    mine = sets[local_rank % len(sets)]
+    quota = cgroup_cpu_quota()
+    if local_world == 1 and quota is not None and quota < len(allowed_cpus()):
+        # one process on (possibly) somebody else's host: the idlest cores near the GPU, not a fixed slice
+        near = node_core_sets(1, procs_per_gpu)
+        wide = rank_core_sets(1, cpus=sibling_order(allowed_cpus()), gpu_cpulists=gpu_local_cpulists() or None)
+        pool = wide[0] if len(wide[0]) > len(near[0]) else near[0]
+        vis = visible_gpu_indices()
+        gpus = gpu_local_cpulists()
+        if gpus and vis and all(0 <= v < len(gpus) for v in vis):   # the visible GPU's own NUMA node
+            nearset = set(c for v in vis for c in gpus[v])
+            pool = [c for c in sibling_order(allowed_cpus()) if c in nearset] or pool
+        mine = pick_idle_cpus(pool, max(1, int(quota + 0.5)))
+    else:
+        sets = node_core_sets(local_world, procs_per_gpu)
+        mine = sets[local_rank % len(sets)]
     try:
         os.sched_setaffinity(0, mine)
     except Exception:

@@ -144,6 +144,26 @@ def test_gpu_numa_topology_is_read_from_sysfs(tmp_path):
     assert sets == [[0, 1], [2, 3], [4, 5]]
 
 
+def test_idle_cores_are_picked_on_a_shared_host():
+    """pick_idle_cpus: two samples of per-cpu ticks; a core is as busy as its busiest hardware
+    thread; whole idle cores first; unreadable /proc/stat falls back to one thread per core."""
+    from oavif_amd import hostinfo
+    cpus = [0, 8, 1, 9, 2, 10, 3, 11]                       # four cores, sibling order
+    core_of = {c: c % 8 for c in cpus}
+    samples = iter([
+        {c: (0, 0) for c in cpus},
+        {0: (95, 100), 8: (0, 100), 1: (0, 100), 9: (0, 100), 2: (50, 100), 10: (0, 100), 3: (1, 100), 11: (0, 100)},
+    ])
+    got = hostinfo.pick_idle_cpus(cpus, 2, core_of=core_of, sampler=lambda: next(samples), sleep=lambda s: None)
+    assert got == [1, 3]                                     # cores 1 and 3 are idle; core 0 is busy on its first thread
+    samples = iter([{c: (0, 0) for c in cpus}, {c: (0, 100) for c in cpus}])
+    assert hostinfo.pick_idle_cpus(cpus, 3, core_of=core_of, sampler=lambda: next(samples), sleep=lambda s: None) == [0, 1, 2]
+    assert hostinfo.pick_idle_cpus(cpus, 3, core_of=core_of, sampler=lambda: {}, sleep=lambda s: None) == [0, 1, 2]
+    assert hostinfo.pick_idle_cpus(cpus, 99, core_of=core_of) == [0, 1, 2, 3, 8, 9, 10, 11]
+    ticks = hostinfo.read_cpu_ticks()
+    assert all(t[1] >= t[0] >= 0 for t in ticks.values())
+
+
 @pytest.fixture(scope="module")
 def varied_dir(tmp_path_factory, hip_lib):
     from PIL import Image
