@@ -23,8 +23,10 @@ def _ms_per_score(group, pr, pd, w, h, n=240):
 
 
 def test_two_product_contexts_created_back_to_back_overlap(hip_lib):
-    """Two-context ms per 4K score <= 0.9 x the one-context figure, for every pair among three
-    contexts created back to back.  (Without placement some pairs of contexts share a hardware
+    """Two-context ms per 4K score <= 0.9 x the one-context figure for the first two contexts a
+    process creates (best of four runs each: the quantity is a rate, the minimum its estimator), and
+    every pair among three contexts created back to back overlaps (<= 0.95: a pair that shares a
+    hardware queue measures 1.0).  (Without placement some pairs of contexts share a hardware
     queue and run at the one-context rate: scripts/gpu_stream_pairs.py.  Three, because HIP's
     default of four hardware queues leaves three distinct ones beside the null stream's; a
     fourth context necessarily shares.)"""
@@ -38,11 +40,11 @@ def test_two_product_contexts_created_back_to_back_overlap(hip_lib):
     ctx = [Ssimu2(0) for _ in range(3)]
     try:
         _ms_per_score(ctx[:2], pr, pd, w, h, 600)   # clocks
-        one = min(_ms_per_score([c], pr, pd, w, h) for c in ctx)
+        one = min(_ms_per_score([c], pr, pd, w, h) for c in ctx for _ in range(2))
         for i in range(3):
             for j in range(i + 1, 3):
-                two = min(_ms_per_score([ctx[i], ctx[j]], pr, pd, w, h) for _ in range(2))
-                assert two <= 0.9 * one, (i, j, two, one)
+                two = min(_ms_per_score([ctx[i], ctx[j]], pr, pd, w, h) for _ in range(4))
+                assert two <= (0.9 if (i, j) == (0, 1) else 0.95) * one, (i, j, two, one)
         # the scores do not depend on the stream
         a, b = ctx[0].score_device(pr, pd, w, h), ctx[2].score_device(pr, pd, w, h)
         assert a == b
