@@ -44,6 +44,7 @@ def test_two_product_contexts_created_back_to_back_overlap(hip_lib):
         for i in range(3):
             for j in range(i + 1, 3):
                 two = min(_ms_per_score([ctx[i], ctx[j]], pr, pd, w, h) for _ in range(4))
+                print(f"contexts {i},{j}: {two:.4f} ms per score on two, {one:.4f} on one, ratio {two / one:.3f}")
                 assert two <= (0.9 if (i, j) == (0, 1) else 0.95) * one, (i, j, two, one)
         # the scores do not depend on the stream
         a, b = ctx[0].score_device(pr, pd, w, h), ctx[2].score_device(pr, pd, w, h)
