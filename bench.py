@@ -87,7 +87,126 @@ def load_counters(size):
     return c
 
 
+def cpu_baseline_child(argv) -> int:
+    """bench.py --cpu-baseline-child CPUS THREADS W H SECONDS MAXREPS: the CPU checker (OpenMP build)
+    timed on one core set in a process of its own -- the affinity is set before the first OpenMP region
+    creates its threads (os.sched_setaffinity reaches only the calling thread of a process that already
+    has threads), and nothing of torch / HIP runs beside it.  Prints one JSON line."""
+    from oavif_amd import hostinfo, synth
+    from oracle import ssimu2_oracle as orc   # checker / CPU timing only
+    cpus, threads, w, h, seconds, maxreps = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), float(argv[4]), int(argv[5])
+    pin_error = ""
+    if cpus != "-":
+        try:
+            os.sched_setaffinity(0, hostinfo.parse_cpulist(cpus))
+        except Exception as e:
+            pin_error = f"{type(e).__name__}: {e}"
+    orc.build()
+    n = orc.set_num_threads(threads)
+    ref = synth.make_ref(w, h, seed=0)
+    dst = synth.distort(ref, "blockq", 2)
+    orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)   # thread pool up
+    ms, score = [], None
+    t_all = time.perf_counter()
+    while len(ms) < maxreps and (len(ms) < 2 or time.perf_counter() - t_all < seconds):
+        t0 = time.perf_counter()
+        score = orc.compute_ssimu2(ref, dst, orc.BLUR_FIR, omp=True)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    out = {"threads": n, "ms": [round(m, 1) for m in ms], "score": score, "pin_error": pin_error,
+           "build": orc.omp_build_name()}
+    if seconds > 5:   # the full run also takes the single-thread figure, on a 1/4-area crop, scaled per pixel
+        crop_r, crop_d = ref[: h // 2, : w // 2], dst[: h // 2, : w // 2]
+        t1 = time.perf_counter()
+        orc.compute_ssimu2(crop_r, crop_d, orc.BLUR_FIR, omp=False)
+        out["single_thread_MPps"] = round((w // 2) * (h // 2) / 1e6 / (time.perf_counter() - t1), 3)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def run_cpu_child(cpus, threads, w, h, seconds, maxreps):
+    import subprocess
+    from oavif_amd import hostinfo
+    arg = hostinfo.format_cpus(cpus) if cpus else "-"
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", arg, str(threads), str(w), str(h),
+                        str(seconds), str(maxreps)], capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        raise RuntimeError(f"cpu_baseline child failed on cpus {arg}: {r.stderr[-400:]}")
+    return json.loads(lines[-1])
+
+
+def _cgroup_cpu_stat():
+    try:
+        return dict((k, int(v)) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat")))
+    except Exception:
+        return {}
+
+
+def measure_cpu_baseline(w, h, mp):
+    """The CPU checker on this host's cores (rank 0, N = 1).  VERDICT r03 item 1: the figure must not depend
+    on which cores a tenant-shared host happens to have free, so (i) the candidates are contiguous slices of
+    whole cores near the GPU, the rank's fixed slice first (hostinfo.candidate_core_sets); (ii) each is timed
+    briefly (2 repetitions) and the fastest is kept; (iii) the full sample runs there, in a process of its
+    own; (iv) everything that decides the number is in the record: cgroup quota and cpuset, the per-core busy
+    fractions of the chosen slice just before, the candidates' probe rates, the thread count that really ran,
+    every repetition's ms, and the cgroup's throttle counters over the run."""
+    from oavif_amd import hostinfo
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()
+    quota = hostinfo.cgroup_cpu_quota()
+    allowed = hostinfo.allowed_cpus()
+    info = {"cgroup_cpu_quota": quota, "affinity_cpus": len(allowed)}
+    try:
+        info["cpuset_effective"] = open("/sys/fs/cgroup/cpuset.cpus.effective").read().strip()
+    except Exception:
+        info["cpuset_effective"] = None
+    try:
+        info["loadavg"] = open("/proc/loadavg").read().split()[0]
+    except Exception:
+        pass
+    pin = quota is not None and quota < len(allowed)
+    cands = hostinfo.candidate_core_sets(threads) if pin else [None]
+    probes = []
+    for cs in cands:
+        try:
+            r = run_cpu_child(cs, threads, w, h, 0.0, 2)
+            probes.append({"cpus": hostinfo.format_cpus(cs) if cs else "unpinned",
+                           "MPps_best_of_2": round(mp / min(r["ms"]) * 1e3, 1)})
+        except Exception as e:
+            probes.append({"cpus": hostinfo.format_cpus(cs) if cs else "unpinned", "error": str(e)[:200]})
+    ok = [i for i, p_ in enumerate(probes) if "MPps_best_of_2" in p_]
+    if not ok:
+        raise RuntimeError(f"no candidate core set could be timed: {probes}")
+    # the fixed slice unless another one is clearly (> 10 %) faster
+    best = max(ok, key=lambda i: probes[i]["MPps_best_of_2"])
+    pick = ok[0] if probes[best]["MPps_best_of_2"] <= 1.10 * probes[ok[0]]["MPps_best_of_2"] else best
+    chosen = cands[pick]
+    busy = hostinfo.busy_fractions(chosen, 1.0) if chosen else {}
+    st0 = _cgroup_cpu_stat()
+    full = run_cpu_child(chosen, threads, w, h, 12.0, 40)
+    st1 = _cgroup_cpu_stat()
+    ms = sorted(full["ms"])
+    med = ms[len(ms) // 2]
+    info.update({"candidates": probes, "chosen": hostinfo.format_cpus(chosen) if chosen else "unpinned",
+                 "chosen_is_fixed_slice": pick == ok[0],
+                 "busy_fraction_of_chosen_before": [round(busy.get(c, -1.0), 2) for c in (chosen or [])],
+                 "ms_per_rep": {"min": ms[0], "median": med, "max": ms[-1], "n": len(ms)},
+                 "cgroup_throttled_periods_during": (st1.get("nr_throttled", 0) - st0.get("nr_throttled", 0)) if st0 else None,
+                 "pin_error": full.get("pin_error", "")})
+    return {
+        "value": round(mp / med * 1e3, 3), "unit": "MP/s", "cores": full["threads"],
+        "pinned_to_cpus": hostinfo.format_cpus(chosen) if chosen else "unpinned", "kind": "port",
+        "sample": f"{len(ms)} x the same {w}x{h} pair (median repetition), oracle/ssimu2_oracle.c (FIR, OpenMP, "
+                  f"{full['threads']} threads, build {full['build']}), in a process of its own pinned to the chosen "
+                  f"slice; not the reference's Zig+fssimu2 (unbuildable here)",
+        "value_best_rep": round(mp / ms[0] * 1e3, 3),
+        "single_thread_value": full.get("single_thread_MPps"),
+        "single_thread_sample": f"1 x {w // 2}x{h // 2} crop, 1 thread",
+        "placement": info, "_score": full["score"]}
+
+
 def main() -> int:
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -571,35 +690,12 @@ def main() -> int:
 
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import ssimu2_oracle as orc
-            from oavif_amd import hostinfo
-            orc.build()
-            # Pin before the first OpenMP region creates its threads: under a cgroup quota far below
-            # the affinity mask (16 of 256 CPUs on the pool's boxes) unpinned threads are throttled,
-            # and the CPU figure comes out a third too low (35-37 vs 53 MP/s, scripts/cpu_oracle_rate.py)
-            pinned = hostinfo.format_cpus(hostinfo.pin_rank(0, 1))
-            cores = orc.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores())
-            orc.compute_ssimu2(ref[:256, :256], dst[:256, :256], orc.BLUR_FIR, omp=True)  # spin up
-            tc = time.perf_counter()
-            reps = 0
-            cpu_score = None
-            while reps < 40 and (time.perf_counter() - tc) < 15.0:
-                cpu_score = orc.compute_ssimu2(ref, dst, orc.BLUR_FIR, omp=True)
-                reps += 1
-            dt = (time.perf_counter() - tc) / reps
-            # single-thread figure on a 1/4-area crop, scaled per pixel
-            crop_r, crop_d = ref[: h // 2, : w // 2], dst[: h // 2, : w // 2]
-            t1 = time.perf_counter()
-            orc.compute_ssimu2(crop_r, crop_d, orc.BLUR_FIR, omp=False)
-            dt1 = time.perf_counter() - t1
-            out["cpu_baseline"] = {
-                "value": round(mp / dt, 3), "unit": "MP/s", "cores": cores, "pinned_to_cpus": pinned, "kind": "port",
-                "sample": f"{reps} x the same {w}x{h} pair, oracle/ssimu2_oracle.c (FIR, "
-                          f"OpenMP, {cores} threads, build {orc.omp_build_name()}); not the "
-                          f"reference's Zig+fssimu2 (unbuildable here)",
-                "single_thread_value": round((w // 2) * (h // 2) / 1e6 / dt1, 3),
-                "single_thread_sample": f"1 x {w // 2}x{h // 2} crop, 1 thread",
-                "score_abs_diff_vs_hip": abs(cpu_score - scores[0])}
+            try:
+                cb = measure_cpu_baseline(w, h, mp)
+                cb["score_abs_diff_vs_hip"] = abs(cb.pop("_score") - scores[0])
+                out["cpu_baseline"] = cb
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:300], "kind": "port"}
         print(json.dumps(out), flush=True)
 
     for sc_ in scorers:

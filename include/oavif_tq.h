@@ -154,11 +154,16 @@ void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v
  * what the encoder and the scorer are fed:
  *     bit depth 16       -> RGBA16, host-endian u16, channels = 4, hbd = true   (io.zig:270-272,292)
  *     8-bit truecolour   -> RGB8, channels = 3                                   (io.zig:275)
- *     everything else    -> RGBA8, channels = 4: gray, gray + alpha, palette, RGBA; tRNS becomes
- *                           alpha, sub-byte gray is scaled to 8 bits             (io.zig:276-280)
- * and the iCCP profile is handed on decompressed (io.zig:261-268).  These two functions are that
- * loader without libspng: the PNG specification over zlib (chunk CRCs, the five row filters,
- * Adam7, PLTE / tRNS / iCCP).  Host code; no GPU involved.
+ *     everything else    -> RGBA8, channels = 4: gray, gray + alpha, palette, RGBA; sub-byte
+ *                           gray is scaled to 8 bits                             (io.zig:276-280)
+ * and the iCCP profile is handed on decompressed (io.zig:261-268).  The reference decodes with
+ * flags 0 (io.zig:285), i.e. without SPNG_DECODE_TRNS: a tRNS chunk is NOT applied and files
+ * without an alpha channel come out opaque (this reading of libspng is unpinned: libspng is not in
+ * the image and the reference holds no PNG fixture).  These two functions are that loader without
+ * libspng: the PNG specification over zlib (chunk CRCs, the five row filters, Adam7, PLTE / iCCP),
+ * inflated scanline by scanline (two rows of memory, whatever the header claims).  A header that
+ * promises more scanline bytes than its IDAT data can inflate to (deflate's 1032 : 1 bound) fails
+ * with OAVIF_PNG_ERR_DECODE in both calls.  Host code; no GPU involved.
  *
  * oavif_png_info_from_memory parses the file and reports the OUTPUT geometry; oavif_png_decode
  * writes `data_bytes` of pixels (2-byte aligned when hbd) and, if `out_icc` is non-NULL, the

@@ -354,6 +354,10 @@ def parse_cli(argv=None):
                          "default: the rank's share of the usable host cores")
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin the rank to its slice of the node's host cores")
+    ap.add_argument("--pin", choices=("slice", "idle"), default=os.environ.get("OAVIF_PIN", "slice") or "slice",
+                    help="slice (default): the rank's fixed contiguous slice of the cores near its GPU; idle: a "
+                         "single rank on a host shared with other tenants may take the idlest cores near its GPU "
+                         "(sampled for 1 s) instead")
     ap.add_argument("--procs-per-gpu", type=int, default=int(os.environ.get("OAVIF_PROCS_PER_GPU", "1") or 1),
                     help="ranks that share one GPU (launch nproc-per-node = GPUs x this): the CPU codec is the "
                          "cost of a pass and several processes per GPU use the host's cores better than one "
@@ -386,11 +390,16 @@ def main(argv=None) -> int:
     # one rank alone is pinned too when the cgroup grants fewer CPUs than the affinity mask holds:
     # a quota is enforced by throttling, and threads that float over the whole host hit it
     quota = hostinfo.cgroup_cpu_quota()
-    pinned = not args.no_pin and (world > 1 or (quota is not None and quota < len(hostinfo.allowed_cpus())))
-    if pinned:
-        mine = hostinfo.pin_rank(local_rank, local_world, procs_per_gpu=ppg)
+    want_pin = not args.no_pin and (world > 1 or (quota is not None and quota < len(hostinfo.allowed_cpus())))
+    pinned, pin_note = False, "not pinned"
+    if want_pin:
+        mine = hostinfo.pin_rank(local_rank, local_world, procs_per_gpu=ppg, idle=(args.pin == "idle"))
+        pinned = mine.pinned
+        if not mine.pinned:   # said, not swallowed: the summary then reads "not pinned"
+            pin_note = f"not pinned: sched_setaffinity failed on rank {rank} ({mine.error})"
+            print(f"oavif_amd.batch: rank {rank}: {pin_note}", file=sys.stderr)
         if world == 1:
-            core_sets = [mine]   # one process under a quota: the idlest cores near the GPU, picked just now
+            core_sets = [list(mine)]
 
     import torch
     import torch.distributed as dist
@@ -455,7 +464,7 @@ def main(argv=None) -> int:
     if rank == 0:
         write_csv(args.output_csv, results)
         print(summarize(results, wall, world))
-        print(f"Host cores per rank{'' if pinned else ' (not pinned)'}: " + "; ".join(
+        print(f"Host cores per rank{'' if pinned else ' (' + pin_note + ')'}: " + "; ".join(
             f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
         print(f"Worker threads per rank: {args.workers}; ranks per GPU: {ppg}; dealing: largest file first")
         print("Note: the stand-in codec (Pillow's libavif) writes 8-bit AVIF where oavif defaults to 10-bit "

@@ -4,8 +4,11 @@
 //       bit depth 16               -> SPNG_FMT_RGBA16  (host-endian u16, 4 channels, hbd = true)
 //       8-bit truecolour           -> SPNG_FMT_RGB8    (3 channels)
 //       everything else            -> SPNG_FMT_RGBA8   (4 channels: gray / gray+alpha / palette /
-//                                     RGBA; tRNS becomes alpha; sub-byte gray scaled to 8 bits)
+//                                     RGBA; sub-byte gray scaled to 8 bits)
 //   and the iCCP profile, decompressed, handed on unchanged (io.zig:261-268).
+//   Decode flags are 0 (io.zig:285), i.e. no SPNG_DECODE_TRNS: a tRNS chunk is NOT applied, files
+//   without an alpha channel come out opaque (alpha 255 / 65535).  libspng is not importable here and
+//   the reference holds no PNG fixture, so this reading of its flags is unpinned.
 //
 // libspng is not in this image and is third-party anyway; this is the PNG specification
 // (signature, chunk CRCs, IHDR / PLTE / tRNS / iCCP / IDAT, zlib inflate, the five row filters,
@@ -34,7 +37,7 @@ struct Span {
 struct Png {
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = 0, interlace = 0;
-    Span plte{nullptr, 0}, trns{nullptr, 0}, iccp{nullptr, 0};
+    Span plte{nullptr, 0}, iccp{nullptr, 0};
     std::vector<Span> idat;
     int samples() const { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4; }
     int bits_per_pixel() const { return samples() * depth; }
@@ -94,8 +97,6 @@ int parse(const uint8_t* buf, size_t len, Png& png) {
         } else if (memcmp(type, "PLTE", 4) == 0) {
             if (seen_idat || clen == 0 || clen % 3 != 0 || clen > 768) return OAVIF_PNG_ERR_DECODE;
             png.plte = Span{data, clen};
-        } else if (memcmp(type, "tRNS", 4) == 0) {
-            if (!seen_idat) png.trns = Span{data, clen};
         } else if (memcmp(type, "iCCP", 4) == 0) {
             if (!seen_idat && !png.plte.p) png.iccp = Span{data, clen};
         } else if (critical) {
@@ -104,14 +105,7 @@ int parse(const uint8_t* buf, size_t len, Png& png) {
     }
     if (png.idat.empty()) return OAVIF_PNG_ERR_DECODE;
     if (png.ctype == 3 && !png.plte.p) return OAVIF_PNG_ERR_DECODE;
-    // tRNS must fit its colour type; a malformed one is ignored like any bad ancillary chunk
-    if (png.trns.p) {
-        const size_t want = png.ctype == 0 ? 2 : png.ctype == 2 ? 6 : 0;
-        if (png.ctype == 4 || png.ctype == 6 || (png.ctype != 3 && png.trns.n != want) ||
-            (png.ctype == 3 && png.trns.n > png.plte.n / 3))
-            png.trns = Span{nullptr, 0};
-    }
-    return OAVIF_PNG_OK;
+    return OAVIF_PNG_OK;  // tRNS is an ancillary chunk this loader does not apply (decode flags 0, see the header)
 }
 
 // iCCP: keyword (1-79 bytes) NUL, compression method 0, zlib stream
@@ -212,7 +206,6 @@ struct Expander {
             switch (png.ctype) {
                 case 0:
                     r = g = b = be16(p);
-                    if (png.trns.p && r == be16(png.trns.p)) a = 0;
                     break;
                 case 4:
                     r = g = b = be16(p);
@@ -220,7 +213,6 @@ struct Expander {
                     break;
                 case 2:
                     r = be16(p), g = be16(p + 2), b = be16(p + 4);
-                    if (png.trns.p && r == be16(png.trns.p) && g == be16(png.trns.p + 2) && b == be16(png.trns.p + 4)) a = 0;
                     break;
                 default:
                     r = be16(p), g = be16(p + 2), b = be16(p + 4), a = be16(p + 6);
@@ -228,7 +220,7 @@ struct Expander {
             o[0] = r, o[1] = g, o[2] = b, o[3] = a;
             return true;
         }
-        if (png.ctype == 2) {  // RGB8: copied as it is (no alpha in this output format, tRNS unused)
+        if (png.ctype == 2) {  // RGB8: copied as it is
             memcpy(out + at * 3, row + i * 3, 3);
             return true;
         }
@@ -238,14 +230,14 @@ struct Expander {
                 const unsigned v = sample8(row, i, d);
                 const uint8_t g = (uint8_t)(d == 8 ? v : v * (255u / ((1u << d) - 1u)));
                 o[0] = o[1] = o[2] = g;
-                o[3] = (png.trns.p && v == (unsigned)(be16(png.trns.p) & ((1u << d) - 1u))) ? 0 : 255;
+                o[3] = 255;
                 return true;
             }
             case 3: {
                 const unsigned idx = sample8(row, i, d);
                 if ((size_t)idx * 3 + 2 >= png.plte.n) return false;
                 memcpy(o, png.plte.p + idx * 3, 3);
-                o[3] = idx < png.trns.n ? png.trns.p[idx] : 255;
+                o[3] = 255;
                 return true;
             }
             case 4:
@@ -268,17 +260,43 @@ const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, 
 
 }  // namespace
 
-extern "C" {
-
-}  // extern "C"
-
 namespace {
+// sub-image sizes of the passes and the bytes of all filtered scanlines (1 filter byte + the row each)
+struct Geometry {
+    int npass;
+    uint32_t pw[7], ph[7];
+    uint64_t filtered_bytes;
+};
+Geometry geometry(const Png& png) {
+    Geometry g;
+    g.npass = png.interlace ? 7 : 1;
+    g.filtered_bytes = 0;
+    for (int k = 0; k < g.npass; ++k) {
+        if (png.interlace) {
+            const Pass& a = kAdam7[k];
+            g.pw[k] = png.w > a.x0 ? (png.w - a.x0 + a.dx - 1) / a.dx : 0;
+            g.ph[k] = png.h > a.y0 ? (png.h - a.y0 + a.dy - 1) / a.dy : 0;
+        } else {
+            g.pw[k] = png.w;
+            g.ph[k] = png.h;
+        }
+        if (g.pw[k] && g.ph[k]) g.filtered_bytes += (uint64_t)g.ph[k] * (1 + row_bytes(png, g.pw[k]));
+    }
+    return g;
+}
+
 // the output geometry of a parsed file (+ its decompressed profile)
 int describe(const Png& png, std::vector<uint8_t>& icc, oavif_png_info* out) {
     const uint64_t px = (uint64_t)png.w * png.h;
     const uint64_t bytes = px * png.out_channels() * (png.hbd() ? 2u : 1u);
     if (px > (1ull << 40) || bytes / png.out_channels() / (png.hbd() ? 2u : 1u) != px || bytes > (uint64_t)SIZE_MAX / 2)
         return OAVIF_PNG_ERR_SIZE;
+    // A header that promises more scanline bytes than its IDAT data can inflate to is a lie (deflate
+    // expands by at most 1032 : 1): fail here, before a caller sizes a buffer from the header -- a
+    // 70-byte file claiming 60000 x 60000 pixels must not cost 10 GB.
+    uint64_t idat_bytes = 0;
+    for (const Span& c : png.idat) idat_bytes += c.n;
+    if (geometry(png).filtered_bytes > idat_bytes * 1032u + 1024u) return OAVIF_PNG_ERR_DECODE;
     const int rc = inflate_icc(png, icc);
     if (rc) return rc;
     out->width = png.w;
@@ -324,67 +342,76 @@ int oavif_png_decode(const uint8_t* png_bytes, size_t len, uint8_t* out_pixels, 
         if (out_cap < info.data_bytes || (info.icc_bytes && out_icc && icc_cap < info.icc_bytes)) return OAVIF_PNG_ERR_SIZE;
         if (info.hbd && (reinterpret_cast<uintptr_t>(out_pixels) & 1u)) return OAVIF_PNG_ERR_ARG;  // u16 output
         if (out_icc && info.icc_bytes) memcpy(out_icc, icc.data(), icc.size());
-        // filtered scanlines of every pass: 1 filter byte + the row
-        size_t need = 0;
-        uint32_t pw[7], ph[7];
-        const int npass = png.interlace ? 7 : 1;
-        for (int k = 0; k < npass; ++k) {
-            if (png.interlace) {
-                const Pass& a = kAdam7[k];
-                pw[k] = png.w > a.x0 ? (png.w - a.x0 + a.dx - 1) / a.dx : 0;
-                ph[k] = png.h > a.y0 ? (png.h - a.y0 + a.dy - 1) / a.dy : 0;
-            } else {
-                pw[k] = png.w;
-                ph[k] = png.h;
-            }
-            if (pw[k] && ph[k]) need += (size_t)ph[k] * (1 + row_bytes(png, pw[k]));
-        }
-        std::vector<uint8_t> raw(need);
+        // Inflate ONE scanline at a time into a pair of row buffers, unfilter it against the row above
+        // and expand it into the caller's pixels: memory is two rows whatever the header claims, and a
+        // stream that ends early fails at the row where it ends (as libspng's progressive decode does).
+        const Geometry geo = geometry(png);
+        size_t max_rb = 0;
+        for (int k = 0; k < geo.npass; ++k)
+            if (geo.pw[k] && geo.ph[k]) max_rb = row_bytes(png, geo.pw[k]) > max_rb ? row_bytes(png, geo.pw[k]) : max_rb;
+        std::vector<uint8_t> rows(2 * (max_rb + 1));
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit(&zs) != Z_OK) return OAVIF_PNG_ERR_OOM;
-        zs.next_out = raw.data();
-        size_t produced = 0;
-        int zrc = Z_OK;
-        for (size_t c = 0; c < png.idat.size() && zrc == Z_OK; ++c) {
-            zs.next_in = const_cast<uint8_t*>(png.idat[c].p);
-            zs.avail_in = (uInt)png.idat[c].n;
-            while (zs.avail_in && zrc == Z_OK) {
-                const size_t room = need - produced;
-                zs.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
+        size_t chunk = 0;
+        bool stream_end = false;
+        zs.next_in = const_cast<uint8_t*>(png.idat[0].p);
+        zs.avail_in = (uInt)png.idat[0].n;
+        // fill dst[0..n) from the zlib stream that runs through the IDAT chunks; false = it ended or broke first
+        auto read_row = [&](uint8_t* dst, size_t n) -> bool {
+            zs.next_out = dst;
+            size_t left = n;
+            while (left) {
+                if (stream_end) return false;
+                if (zs.avail_in == 0) {
+                    if (++chunk >= png.idat.size()) return false;  // truncated
+                    zs.next_in = const_cast<uint8_t*>(png.idat[chunk].p);
+                    zs.avail_in = (uInt)png.idat[chunk].n;
+                    continue;
+                }
+                zs.avail_out = (uInt)(left > 0x40000000u ? 0x40000000u : left);
                 const size_t before = zs.avail_out;
-                zrc = inflate(&zs, Z_NO_FLUSH);
-                produced += before - zs.avail_out;
-                zs.next_out = raw.data() + produced;
-                if (produced == need && zrc == Z_OK) zrc = Z_STREAM_END;  // trailing data is ignored
+                const int zrc = inflate(&zs, Z_NO_FLUSH);
+                left -= before - zs.avail_out;
+                if (zrc == Z_STREAM_END) stream_end = true;
+                else if (zrc != Z_OK && !(zrc == Z_BUF_ERROR && zs.avail_in == 0)) return false;
             }
-        }
-        inflateEnd(&zs);
-        if (produced != need || (zrc != Z_STREAM_END && zrc != Z_OK)) return OAVIF_PNG_ERR_DECODE;
+            return true;
+        };
         const size_t bpp = (size_t)(png.bits_per_pixel() + 7) / 8;
         const Expander ex{png, out_pixels};
-        size_t off = 0;
-        std::vector<uint8_t> zero;
-        for (int k = 0; k < npass; ++k) {
-            if (!pw[k] || !ph[k]) continue;
-            const size_t rb = row_bytes(png, pw[k]);
-            zero.assign(rb, 0);
-            const uint8_t* prev = zero.data();
+        int result = OAVIF_PNG_OK;
+        for (int k = 0; k < geo.npass && result == OAVIF_PNG_OK; ++k) {
+            if (!geo.pw[k] || !geo.ph[k]) continue;
+            const size_t rb = row_bytes(png, geo.pw[k]);
+            uint8_t* cur = rows.data();
+            uint8_t* prev = rows.data() + max_rb + 1;
+            memset(prev, 0, rb + 1);  // a pass's first row has zeros above it
             const Pass a = png.interlace ? kAdam7[k] : Pass{0, 0, 1, 1};
-            for (uint32_t j = 0; j < ph[k]; ++j) {
-                uint8_t* row = raw.data() + off + 1;
-                if (unfilter(raw[off], row, prev, rb, bpp)) return OAVIF_PNG_ERR_DECODE;
+            for (uint32_t j = 0; j < geo.ph[k]; ++j) {
+                if (!read_row(cur, 1 + rb) || unfilter(cur[0], cur + 1, prev + 1, rb, bpp)) {
+                    result = OAVIF_PNG_ERR_DECODE;
+                    break;
+                }
+                const uint8_t* row = cur + 1;
                 const uint32_t y = a.y0 + j * a.dy;
                 if (!png.interlace && png.depth == 8 && (png.ctype == 2 || png.ctype == 6)) {
                     memcpy(out_pixels + (size_t)y * rb, row, rb);  // RGB8 / RGBA8 rows go out as they are
                 } else {
-                    for (uint32_t i = 0; i < pw[k]; ++i)
-                        if (!ex.put(row, i, a.x0 + i * a.dx, y)) return OAVIF_PNG_ERR_DECODE;
+                    for (uint32_t i = 0; i < geo.pw[k]; ++i)
+                        if (!ex.put(row, i, a.x0 + i * a.dx, y)) {
+                            result = OAVIF_PNG_ERR_DECODE;
+                            break;
+                        }
+                    if (result != OAVIF_PNG_OK) break;
                 }
-                prev = row;
-                off += 1 + rb;
+                uint8_t* t = cur;
+                cur = prev;
+                prev = t;
             }
         }
+        inflateEnd(&zs);  // data behind the last scanline is ignored
+        if (result != OAVIF_PNG_OK) return result;
     } catch (const std::bad_alloc&) {
         return OAVIF_PNG_ERR_OOM;
     } catch (...) {

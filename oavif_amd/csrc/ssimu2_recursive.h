@@ -123,6 +123,20 @@ typedef float rg_f4u __attribute__((ext_vector_type(4), aligned(4)));  // a row 
 #ifndef RG_NT_HLD
 #define RG_NT_HLD 0  // horizontal pass: loads of the XYB planes
 #endif
+// Diagnosis builds only (scripts/gpu_rg_exp.sh; results are garbage, timings are the point):
+// what bounds a stage when its HBM stream is taken away.
+#ifndef RG_EXP_H_NOSTORE
+#define RG_EXP_H_NOSTORE 0   // horizontal pass without its global stores
+#endif
+#ifndef RG_EXP_H_SAMETILE
+#define RG_EXP_H_SAMETILE 0  // horizontal pass loading tile 0 over and over (cache-fed)
+#endif
+#ifndef RG_EXP_V_SAMEROWS
+#define RG_EXP_V_SAMEROWS 0  // vertical pass loading rows 0-9 of every plane over and over (cache-fed)
+#endif
+#ifndef RG_EXP_V_REVERSE
+#define RG_EXP_V_REVERSE 0   // vertical pass: column groups right to left (most recently written first)
+#endif
 
 // Staging of the horizontal pass.  A lane that streamed its own row (round 2, and the first
 // round-3 form: 16-byte loads, 20 rows per wave) hands the memory pipeline one request PER LANE --
@@ -167,8 +181,9 @@ __device__ __forceinline__ void rg_h_fetch(const RgLine& L, rg_f4 (&ra)[RG_TR], 
     // outside the row
 #pragma unroll
     for (int i = 0; i < RG_TR; ++i) {
-        const float* pa = L.ga + ((size_t)L.goff[i] + (size_t)T * RG_TW);
-        const float* pb = L.gb + ((size_t)L.goff[i] + (size_t)T * RG_TW);
+        const size_t toff = RG_EXP_H_SAMETILE ? 0 : (size_t)T * RG_TW;
+        const float* pa = L.ga + ((size_t)L.goff[i] + toff);
+        const float* pb = L.gb + ((size_t)L.goff[i] + toff);
         if (RG_NT_HLD) {
             ra[i] = __builtin_nontemporal_load(reinterpret_cast<const rg_f4u*>(pa));
             if (OPK == 2) rb[i] = __builtin_nontemporal_load(reinterpret_cast<const rg_f4u*>(pb));
@@ -187,6 +202,7 @@ __device__ __forceinline__ void rg_h_fetch(const RgLine& L, rg_f4 (&ra)[RG_TR], 
 template <bool EDGE>
 __device__ __forceinline__ void rg_h_store(const RgLine& L, const RgRing& tout, int S) {
     const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
+    if (RG_EXP_H_NOSTORE) return;
 #pragma unroll
     for (int i = 0; i < RG_TR; ++i) {
         const rg_f4 v = *reinterpret_cast<const rg_f4*>(&tout[4 * i + rr][((S & 1) * RG_TW) + 4 * cc]);
@@ -383,8 +399,8 @@ __device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w,
     float q[RG_PF][RG_VB];  // queue slot b % PF holds rows 10 b .. 10 b + 9, as loaded
 #define RG_V_LOAD(B, SLOT)                                          \
     _Pragma("unroll") for (int j = 0; j < RG_VB; ++j)               \
-        q[SLOT][j] = RG_NT_LD ? __builtin_nontemporal_load(in + (size_t)min((B) * RG_VB + j, h - 1) * w) \
-                           : in[(size_t)min((B) * RG_VB + j, h - 1) * w];
+        q[SLOT][j] = RG_NT_LD ? __builtin_nontemporal_load(in + (size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * w) \
+                           : in[(size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * w];
 #pragma unroll
     for (int j = 0; j < RG_VB; ++j) q[RG_PF - 1][j] = 0.f;  // batch -1: rows -10 .. -1
     RG_V_LOAD(0, 0)
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
             first = p.vblk_end[s];
         }
     const int blk = (int)blockIdx.x - first;
-    const int ch = blk % 3, cg = blk / 3;
+    const int ch = blk % 3, cg = RG_EXP_V_REVERSE ? p.vgroups[sc] - 1 - blk / 3 : blk / 3;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int w = p.w[sc], h = p.h[sc];
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
         float g[RG_PF][2][4];
 #define RG_M_LOAD(B, SLOT)                                                     \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                         \
-        const int r_ = (B) * RG_VB + j0 + jj - (RG_N - 1);                     \
+        const int r_ = (RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j0 + jj - (RG_N - 1); \
         const size_t o_ = (size_t)min(max(r_, 0), h - 1) * w;                  \
         g[SLOT][jj][0] = RG_NT_LD ? __builtin_nontemporal_load(g_mu1 + o_) : g_mu1[o_]; \
         g[SLOT][jj][1] = RG_NT_LD ? __builtin_nontemporal_load(g_s11 + o_) : g_s11[o_]; \

@@ -212,14 +212,18 @@ def read_cpu_ticks(path: str = "/proc/stat") -> Dict[int, tuple]:
     return out
 
 
-def pick_idle_cpus(cpus: Sequence[int], n: int, sample_s: float = 0.1, core_of: Optional[Dict[int, int]] = None,
+def pick_idle_cpus(cpus: Sequence[int], n: int, sample_s: float = 1.0, core_of: Optional[Dict[int, int]] = None,
                    sampler=read_cpu_ticks, sleep=None) -> List[int]:
-    """The `n` least busy of `cpus` over a short sample of /proc/stat, whole physical cores first
-    (a core counts as busy as its busiest hardware thread).  For a job that shares its host with
-    other tenants: a fixed slice of the host is fine on a node one owns, but on a shared host it may
-    be exactly where somebody else's threads are (measured: the same pinned OpenMP run 61 MP/s on
-    idle cores, 28 MP/s on cores another tenant was using).  Falls back to the first n of
-    one_thread_per_core_first(cpus) when /proc/stat does not help."""
+    """The `n` least busy of `cpus` over a sample of /proc/stat, whole physical cores first (a core
+    counts as busy as its busiest hardware thread).  OPT-IN only (pin_rank(idle=True) /
+    OAVIF_PIN=idle), for a host one shares with other tenants whose threads sit on the fixed slice.
+    It is not the default: round 3 made it one with a 0.1 s sample (10 scheduler ticks) and the
+    driver's run then measured the OpenMP checker at 14 MP/s on the picked set against 55-61 on the
+    fixed slice -- a scattered set costs locality (GPU box, r04: 43 MP/s on sixteen idle cores spread
+    over two NUMA nodes, 51 on sixteen scattered over one, 55 on cores 0-15: profiles/r04_pin_diag.log),
+    a short sample reads another tenant's momentarily blocked cores as idle, and a pinned thread cannot
+    leave a core that turns out busy.  Falls back to the first n of one_thread_per_core_first(cpus)
+    when /proc/stat does not help."""
     import time as _time
     cpus = list(cpus)
     order = one_thread_per_core_first(cpus, core_of)
@@ -246,37 +250,95 @@ def pick_idle_cpus(cpus: Sequence[int], n: int, sample_s: float = 0.1, core_of: 
         g = core_of.get(c, c)
         nth[c] = seen.get(g, 0)
         seen[g] = nth[c] + 1
-    # one thread of every core before any second thread; among those the idlest cores; ties in the given order
-    chosen = sorted(cpus, key=lambda c: (nth[c], round(core_busy[core_of.get(c, c)], 2), rank[c]))[:n]
+    # one thread of every core before any second thread; among those the idlest cores (in steps of 10 %:
+    # cores that are about equally idle stay in the given order, i.e. contiguous); ties in the given order
+    chosen = sorted(cpus, key=lambda c: (nth[c], round(core_busy[core_of.get(c, c)], 1), rank[c]))[:n]
     return sorted(chosen, key=lambda c: rank[c])
 
 
-def pin_rank(local_rank: int, local_world: int, procs_per_gpu: int = 1) -> List[int]:
-    """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
-    before the first GPU call and before any thread pool exists.  Returns the set.
+def busy_fractions(cpus: Sequence[int], sample_s: float = 1.0, sampler=read_cpu_ticks, sleep=None) -> Dict[int, float]:
+    """cpu id -> fraction of `sample_s` it was not idle ({} when /proc/stat cannot be read)."""
+    import time as _time
+    a = sampler()
+    (sleep or _time.sleep)(sample_s)
+    b = sampler()
+    out: Dict[int, float] = {}
+    for c in cpus:
+        if c in a and c in b and b[c][1] > a[c][1]:
+            out[c] = (b[c][0] - a[c][0]) / (b[c][1] - a[c][1])
+    return out
 
-    Worth doing for a single rank too when a cgroup quota is far below the affinity mask: 16
-    encoder threads floating over the 256 CPUs of the GPU host under a 16-CPU quota ran 22 images/s,
-    pinned to 16 cores 45 (the quota is enforced by throttling, which a pinned job never hits)."""
+
+def gpu_near_pool(procs_per_gpu: int = 1) -> List[int]:
+    """The allowed cpus of the NUMA node(s) the visible GPU(s) hang off, hardware threads of a core
+    neighbours; the whole allowed set when sysfs or *_VISIBLE_DEVICES do not say."""
+    allowed = sibling_order(allowed_cpus())
+    gpus = gpu_local_cpulists()
+    vis = visible_gpu_indices()
+    if gpus and vis and all(0 <= v < len(gpus) for v in vis):
+        nearset = set(c for v in vis for c in gpus[v])
+        near = [c for c in allowed if c in nearset]
+        if near:
+            return near
+    if gpus:
+        nearset = set(gpus[0])
+        near = [c for c in allowed if c in nearset]
+        if near:
+            return near
+    return allowed
+
+
+def candidate_core_sets(n: int, max_sets: int = 3) -> List[List[int]]:
+    """Contiguous slices of `n` whole cores near the GPU, the rank's fixed slice (what pin_rank
+    takes) first: what bench.py's cpu_baseline times briefly before it keeps the fastest, so that
+    another tenant's threads on one slice do not become this repo's "CPU baseline"."""
+    first = node_core_sets(1)[0]
+    pool = one_thread_per_core_first(gpu_near_pool())
+    sets = [list(first)]
+    taken = set(first)
+    rest = [c for c in pool if c not in taken]
+    while len(sets) < max_sets and len(rest) >= n:
+        sets.append(rest[:n])
+        rest = rest[n:]
+    return sets
+
+
+class PinResult(list):
+    """The core set of a rank (a list of cpu ids) + whether the kernel accepted it."""
+    pinned: bool = True
+    error: str = ""
+    how: str = "fixed slice"
+
+
+def pin_rank(local_rank: int, local_world: int, procs_per_gpu: int = 1, idle: Optional[bool] = None) -> PinResult:
+    """Restrict this process (and every thread it starts later) to its rank's core set.  Call it
+    before the first GPU call and before any thread pool exists.  Returns the set as a PinResult:
+    `.pinned` is False (and `.error` says why) when sched_setaffinity refused -- the rank then
+    runs wherever the launcher put it and the caller's summary must say so.
+
+    Every rank takes its deterministic slice of the cores near its GPU (node_core_sets): contiguous
+    whole cores, one hardware thread per core first, cut to the rank's share of the cgroup quota.
+    Worth doing for a single rank too when the quota is far below the affinity mask: 16 encoder
+    threads floating over the 256 CPUs of the GPU host under a 16-CPU quota ran 22 images/s, pinned
+    to 16 cores 45 (a quota is enforced by throttling, which a pinned job never hits).
+    `idle=True` (or OAVIF_PIN=idle), single rank only: the idlest cores near the GPU over a 1 s
+    sample instead -- opt-in, see pick_idle_cpus for why it is not the default."""
+    if idle is None:
+        idle = os.environ.get("OAVIF_PIN", "") == "idle"
     quota = cgroup_cpu_quota()
-    if local_world == 1 and quota is not None and quota < len(allowed_cpus()):
-        # one process on (possibly) somebody else's host: the idlest cores near the GPU, not a fixed slice
-        near = node_core_sets(1, procs_per_gpu)
-        wide = rank_core_sets(1, cpus=sibling_order(allowed_cpus()), gpu_cpulists=gpu_local_cpulists() or None)
-        pool = wide[0] if len(wide[0]) > len(near[0]) else near[0]
-        vis = visible_gpu_indices()
-        gpus = gpu_local_cpulists()
-        if gpus and vis and all(0 <= v < len(gpus) for v in vis):   # the visible GPU's own NUMA node
-            nearset = set(c for v in vis for c in gpus[v])
-            pool = [c for c in sibling_order(allowed_cpus()) if c in nearset] or pool
-        mine = pick_idle_cpus(pool, max(1, int(quota + 0.5)))
-    else:
-        sets = node_core_sets(local_world, procs_per_gpu)
-        mine = sets[local_rank % len(sets)]
+    sets = node_core_sets(local_world, procs_per_gpu)
+    mine = PinResult(sets[local_rank % len(sets)])
+    if idle and local_world == 1 and quota is not None and quota < len(allowed_cpus()):
+        n = max(1, int(quota + 0.5))
+        picked = pick_idle_cpus(gpu_near_pool(procs_per_gpu), n, sample_s=1.0)
+        if picked:
+            mine = PinResult(picked)
+            mine.how = "idlest cores near the GPU over 1 s"
     try:
-        os.sched_setaffinity(0, mine)
-    except Exception:
-        pass  # not fatal: the rank then runs wherever the launcher put it
+        os.sched_setaffinity(0, list(mine))
+    except Exception as e:   # reported, not fatal
+        mine.pinned = False
+        mine.error = f"{type(e).__name__}: {e}"
     return mine
 
 

@@ -5,7 +5,9 @@ specification over zlib; no libspng, no Pillow).
     16-bit file        -> (h, w, 4) uint16, hbd = True     (RGBA16, io.zig:270-272)
     8-bit truecolour   -> (h, w, 3) uint8                  (RGB8,   io.zig:275)
     everything else    -> (h, w, 4) uint8                  (RGBA8: gray, gray+alpha, palette, RGBA;
-                                                            tRNS becomes alpha; io.zig:276-280)
+                                                            io.zig:276-280)
+tRNS is not applied (decode flags 0 at io.zig:285: no SPNG_DECODE_TRNS), so alpha is opaque unless the
+file has an alpha channel.
 """
 from __future__ import annotations
 
@@ -46,8 +48,11 @@ def load_png(buf: bytes):
     rc = L.oavif_png_info_from_memory(arr, len(buf), ctypes.byref(info))
     if rc != 0:
         raise PngError(rc)
-    out = np.empty((info.height, info.width, info.channels), np.uint16 if info.hbd else np.uint8)
-    icc = np.empty(info.icc_bytes, np.uint8) if info.icc_bytes else None
+    try:
+        out = np.empty((info.height, info.width, info.channels), np.uint16 if info.hbd else np.uint8)
+        icc = np.empty(info.icc_bytes, np.uint8) if info.icc_bytes else None
+    except MemoryError:
+        raise PngError(-5) from None
     rc = L.oavif_png_decode(arr, len(buf), out.ctypes.data_as(ctypes.c_void_p), out.nbytes,
                             icc.ctypes.data_as(ctypes.c_void_p) if icc is not None else None,
                             info.icc_bytes)

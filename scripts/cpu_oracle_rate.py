@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from oavif_amd import hostinfo, synth  # noqa: E402
 
 if len(sys.argv) > 1 and sys.argv[1] == "pin":
-    print("pinned to", hostinfo.format_cpus(hostinfo.pin_rank(0, 1)))
+    print("pinned to", hostinfo.format_cpus(hostinfo.pin_rank(0, 1, idle=(len(sys.argv) > 2 and sys.argv[2] == "idle"))))
 from oracle import ssimu2_oracle as orc  # noqa: E402
 
 orc.build()

@@ -106,6 +106,28 @@ int main(int argc, char** argv) {
             printf("a valid seed failed to decode\n");
             return 1;
         }
+    // lying headers: the IHDR of a small valid file rewritten to claim a huge image, CRC
+    // repaired.  The info call itself must refuse what the IDAT bytes cannot inflate to (1032 : 1), so no
+    // caller sizes gigabytes from it; the decode is called directly with a small buffer as well.
+    {
+        static const uint32_t dims[][2] = {{60000, 60000}, {0x7FFFFFFF, 2}, {2, 0x7FFFFFFF}, {1u << 20, 1u << 20}};
+        for (const Bytes& s : seeds)
+            for (auto& d : dims) {
+                Bytes m = s;
+                for (int k = 0; k < 4; ++k) m[16 + k] = (uint8_t)(d[0] >> (24 - 8 * k)), m[20 + k] = (uint8_t)(d[1] >> (24 - 8 * k));
+                fix_crc(m, 16);
+                oavif_png_info info;
+                if (oavif_png_info_from_memory(m.data(), m.size(), &info) == OAVIF_PNG_OK) {
+                    printf("a header claiming %u x %u over %zu bytes of file was accepted\n", d[0], d[1], m.size());
+                    return 1;
+                }
+                uint16_t small[64];
+                if (oavif_png_decode(m.data(), m.size(), (uint8_t*)small, sizeof small, nullptr, 0) == OAVIF_PNG_OK) {
+                    printf("a lying header decoded\n");
+                    return 1;
+                }
+            }
+    }
     long ok = 0, rejected = 0;
     for (int r = 0; r < rounds; ++r)
         for (const Bytes& s : seeds) {

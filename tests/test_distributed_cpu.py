@@ -164,6 +164,39 @@ def test_idle_cores_are_picked_on_a_shared_host():
     assert all(t[1] >= t[0] >= 0 for t in ticks.values())
 
 
+def test_pin_rank_takes_the_fixed_slice_and_reports_a_refused_affinity(monkeypatch):
+    """the default placement is the deterministic slice (idle picking is opt-in:
+    its round-3 default, a 0.1 s sample, cost the driver-run cpu_baseline a factor of four); a failed
+    sched_setaffinity is reported in the result, not swallowed."""
+    from oavif_amd import hostinfo
+    cpus = list(range(32))
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: cpus)
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 4.0)
+    monkeypatch.setattr(hostinfo, "gpu_local_cpulists", lambda sysfs="/sys": [])
+    monkeypatch.setattr(hostinfo, "sibling_order", lambda c, sysfs="/sys": list(c))
+    monkeypatch.delenv("OAVIF_PIN", raising=False)
+    calls = []
+    monkeypatch.setattr(hostinfo.os, "sched_setaffinity", lambda pid, mask: calls.append(sorted(mask)))
+    sampled = []
+    monkeypatch.setattr(hostinfo, "pick_idle_cpus", lambda pool, n, sample_s=1.0, **k: sampled.append(sample_s) or list(pool)[8:8 + n])
+    got = hostinfo.pin_rank(0, 1)
+    assert list(got) == [0, 1, 2, 3] and got.pinned and got.how == "fixed slice" and calls[-1] == [0, 1, 2, 3] and not sampled
+    got = hostinfo.pin_rank(0, 1, idle=True)                       # opt-in: a 1 s sample, never 0.1
+    assert list(got) == [8, 9, 10, 11] and sampled == [1.0] and got.pinned
+    monkeypatch.setenv("OAVIF_PIN", "idle")
+    assert list(hostinfo.pin_rank(0, 1)) == [8, 9, 10, 11]
+    assert list(hostinfo.pin_rank(1, 2)) == [16, 17]               # ranks of a multi-rank job keep their slices
+    monkeypatch.delenv("OAVIF_PIN")
+
+    def refuse(pid, mask):
+        raise PermissionError("not permitted")
+    monkeypatch.setattr(hostinfo.os, "sched_setaffinity", refuse)
+    got = hostinfo.pin_rank(0, 1)
+    assert list(got) == [0, 1, 2, 3] and not got.pinned and "PermissionError" in got.error
+    # candidates for bench.py's cpu_baseline: the fixed slice first, then the following contiguous slices
+    assert hostinfo.candidate_core_sets(4) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]
+
+
 @pytest.fixture(scope="module")
 def varied_dir(tmp_path_factory, hip_lib):
     from PIL import Image

@@ -1,6 +1,8 @@
 """Native PNG ingest (oavif_amd/csrc/png_ingest.cpp through oavif_amd.png) against the output
 rules of the reference's loader, /root/reference/src/io.zig:242-307 (libspng, flags 0):
-16-bit -> RGBA16 + hbd, 8-bit truecolour -> RGB8, everything else -> RGBA8 with tRNS as alpha.
+16-bit -> RGBA16 + hbd, 8-bit truecolour -> RGB8, everything else -> RGBA8.  Decode flags are 0 (io.zig:285), so a
+tRNS chunk is not applied: files without an alpha channel decode opaque (libspng applies tRNS only under
+SPNG_DECODE_TRNS; libspng is not importable here, so that reading is this repo's -- unpinned).
 
 The expected pixels are computed here from the arrays the test files are made of (a small PNG
 WRITER below covers every colour type, bit depth, row filter, Adam7 and the ancillary chunks);
@@ -93,6 +95,7 @@ def write_png(samples: np.ndarray, ctype: int, depth: int, interlace: bool = Fal
 
 # ---- the reference's output rules (io.zig:270-290) restated for the expectation ----------------------
 def expected(samples, ctype, depth, plte=None, trns=None):
+    trns = None  # spng_decode_image(..., flags = 0) at io.zig:285: no SPNG_DECODE_TRNS, the chunk is not applied
     h, w, s = samples.shape
     smp = samples.astype(np.int64)
     if depth == 16:
@@ -230,6 +233,43 @@ def test_errors_carry_the_references_names(hip_lib):
     # a zlib stream that ends before the last scanline
     raw = zlib.compress(bytes(3 * (1 + 6 * 3)))            # three of the seven rows
     assert err(good[:33] + _chunk(b"IDAT", raw) + _chunk(b"IEND", b"")) == "DecodeFailed"
+
+
+def test_a_header_that_lies_about_its_size_fails_at_once(hip_lib):
+    """a 70-byte file whose IHDR claims 60000 x 60000 must not cost 10 GB or 100 s -- neither
+    in the info call (callers size their buffer from it) nor in the decode; libspng fails such a file as
+    soon as its stream ends."""
+    import time
+    smp = np.zeros((7, 6, 3), np.int64)
+    good = write_png(smp, 2, 8)
+    for (w, h, ctype, depth) in ((60000, 60000, 2, 8), (0x7FFFFFFF, 3, 6, 16), (200000, 200000, 0, 1)):
+        lie = good[:8] + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + good[33:]
+        t = time.perf_counter()
+        with pytest.raises(png.PngError) as ei:
+            png.png_info(lie)
+        assert ei.value.name in ("DecodeFailed", "ImageSizeFailed")
+        with pytest.raises(png.PngError):
+            png.load_png(lie)
+        assert time.perf_counter() - t < 1.0
+    # a stream that could hold the claimed image by the 1032 : 1 bound but ends early: fails at the row
+    # where it ends, with two rows of memory (the decode inflates scanline by scanline)
+    w, h = 20000, 20000
+    body = zlib.compress(bytes(1000 * (1 + 3 * w)), 9)           # 1000 of the 20000 rows, ~60 KB
+    pad = _chunk(b"IDAT", body) + _chunk(b"IDAT", bytes(1 + (h * (1 + 3 * w)) // 1032 - len(body)))
+    lie = good[:8] + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + pad + _chunk(b"IEND", b"")
+    assert png.png_info(lie).data_bytes == 3 * w * h
+    t = time.perf_counter()
+    with pytest.raises(png.PngError) as ei:
+        png.load_png(lie)
+    assert ei.value.name == "DecodeFailed" and time.perf_counter() - t < 5.0
+
+
+def test_an_unallocatable_output_is_out_of_memory_not_a_traceback(hip_lib, monkeypatch):
+    smp = np.zeros((7, 6, 3), np.int64)
+    monkeypatch.setattr(png.np, "empty", lambda *a, **k: (_ for _ in ()).throw(MemoryError()))
+    with pytest.raises(png.PngError) as ei:
+        png.load_png(write_png(smp, 2, 8))
+    assert ei.value.name == "OutOfMemory"
 
 
 def test_cli_loads_png_through_the_native_decoder(hip_lib, tmp_path, monkeypatch):
