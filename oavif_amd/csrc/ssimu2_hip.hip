@@ -158,6 +158,8 @@ struct ssimu2_ctx {
     float* d_rg = nullptr;
     size_t cap_rg = 0;            // floats
     double* d_rg_part = nullptr;  // [scale][18][column groups]
+    unsigned* d_rg_q = nullptr;   // job cursors of the persistent recursive-mode kernels (4 words)
+    int num_cus = 0;              // workgroups of those kernels: one per CU
     size_t cap_rg_part = 0;       // doubles
     float* d_rg_dbg = nullptr;    // instrumented builds: 15 + 15 raw planes of scale rg_dbg_scale
     size_t cap_rg_dbg = 0;
@@ -259,6 +261,8 @@ void free_recursive(ssimu2_ctx* c) {
     (void)hipFree(c->d_rg);
     (void)hipFree(c->d_rg_part);
     (void)hipFree(c->d_rg_dbg);
+    (void)hipFree(c->d_rg_q);
+    c->d_rg_q = nullptr;
     c->d_rg = c->d_rg_dbg = nullptr;
     c->d_rg_part = nullptr;
     c->cap_rg = c->cap_rg_part = c->cap_rg_dbg = 0;
@@ -421,6 +425,12 @@ int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
         c->cap_rg = need;
         c->cap_rg_part = need_part;
     }
+    if (!c->d_rg_q) {
+        HIP_TRY(c, hipMalloc(&c->d_rg_q, 4 * sizeof(unsigned)));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        c->num_cus = cus;
+    }
     if (c->rg_dbg_scale >= 0 && c->rg_dbg_scale < p.nscales) {
         const size_t nd = (size_t)24 * p.w[c->rg_dbg_scale] * p.h[c->rg_dbg_scale] + 16;  // 15 h planes + 9 v planes
         if (nd > c->cap_rg_dbg) {
@@ -469,6 +479,14 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, bool ref_frame, RgPlan
         poff += (size_t)kStats * rp->vgroups[s];
     }
     rp->dump = hbuf + 9 * ntot;
+    // jobs of the persistent kernels: horizontal = one plane of one channel over 20 rows (NK planes
+    // per channel), vertical = one channel of 64 columns; both listed largest scale first
+    const int nk = ref_frame ? 2 : 3;
+    for (int s = 0; s < p.nscales; ++s) rp->hjob_end[s] = rp->hblk_end[s] * nk;
+    rp->hjobs = hb_ * nk;
+    rp->hlong = rp->hjobs < (RG_HW / 2) * c->num_cus ? rp->hjobs : (RG_HW / 2) * c->num_cus;
+    rp->vjobs = vb_;
+    rp->q = c->d_rg_q;
     *hblocks = hb_;
     *vblocks = vb_;
 }
@@ -507,8 +525,23 @@ void rg_launch_convert(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, 
     float* none[1] = {nullptr};
     PyrBandArgs a = pyramid_args(p, 1, frames, none);
     a.xyb0[0] = rp.xout[0];
+    a.zero4 = rp.q;
     for (int l = 0; l < a.nlevels; ++l) a.out[0][l] = rp.xout[l + 1];
     hipLaunchKernelGGL(k_pyramid_bands_xyb, dim3(a.bands_x * a.bands_y), dim3(PYR_THREADS), 0, c->stream, a);
+}
+
+// The horizontal pass: one workgroup per 20 rows and channel (RG_H_PERSISTENT = 1, an A/B build: one
+// workgroup per CU pulling jobs, ssimu2_recursive.h).
+template <bool REF>
+void rg_launch_h(ssimu2_ctx* c, bool fma, int hblocks, const RgPlan& rp) {
+    if (hblocks <= 0) return;
+#if RG_H_PERSISTENT
+    if (fma) hipLaunchKernelGGL((k_rg_h_persistent<true, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
+    else hipLaunchKernelGGL((k_rg_h_persistent<false, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
+#else
+    if (fma) hipLaunchKernelGGL((k_rg_h<true, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
+    else hipLaunchKernelGGL((k_rg_h<false, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
+#endif
 }
 
 // What depends on the reference alone: its XYB planes and mu1 = blur(x), s11 = blur(x * x) at
@@ -521,8 +554,7 @@ void rg_enqueue_reference(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref)
     for (int s = 0; s < p.nscales; ++s) rp.emit[s] = rp.cache[s];
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
     rg_launch_convert(c, p, d_ref, rp);
-    if (fma) hipLaunchKernelGGL((k_rg_h<true, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
-    else hipLaunchKernelGGL((k_rg_h<false, true>), dim3(hblocks), dim3(128), 0, c->stream, rp);
+    rg_launch_h<true>(c, fma, hblocks, rp);
     if (dbg) rg_debug_keep_h(c, p, rp, true);
     if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
     else hipLaunchKernelGGL((k_rg_v_emit<false, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
@@ -537,11 +569,10 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
     if (p.nscales > 0) {  // a frame below 8 x 8 has no scale to score
         rg_launch_convert(c, p, d_dist, rp);
-        const int lds_h = rg_extra_lds("OAVIF_RG_LDS_H"), lds_v = rg_extra_lds("OAVIF_RG_LDS_V");
-        if (fma) hipLaunchKernelGGL((k_rg_h<true, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_h<false, false>), dim3(hblocks), dim3(192), lds_h, c->stream, rp);
-        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vblocks), dim3(512), lds_v, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vblocks), dim3(512), lds_v, c->stream, rp);
+        const int vgrid = vblocks < c->num_cus ? vblocks : c->num_cus;
+        rg_launch_h<false>(c, fma, hblocks, rp);
+        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vgrid), dim3(512), RG_V_PAD_BYTES, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vgrid), dim3(512), RG_V_PAD_BYTES, c->stream, rp);
         if (dbg) {
             rg_debug_keep_h(c, p, rp, false);
             const int s = c->rg_dbg_scale;

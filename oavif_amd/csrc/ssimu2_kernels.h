@@ -176,6 +176,7 @@ struct PyrBandArgs {
     int w[6], h[6];        // level dimensions, [0] = the 8-bit frame
     int nlevels;           // levels to produce: 1..5; 0 = nothing to do
     int bands_x, bands_y, nframes;
+    unsigned* zero4;       // XYB variant: four job cursors of the recursive passes that follow in the stream, zeroed here
 };
 
 constexpr int PYR_THREADS = 512;                      // (256-thread bands of 128 pixels measured the same)
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands_xyb(PyrBandArgs a
     __shared__ float s_lut[256];
     __shared__ float s_tiles[PYR_BAND_LDS_FLOATS];
     if (threadIdx.x < 256) s_lut[threadIdx.x] = c_k.lut[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 4 && a.zero4) a.zero4[threadIdx.x] = 0u;  // k_rg_h / k_rg_v start after this launch has ended
     __syncthreads();
     pyramid_band<true>(a, (int)blockIdx.x, s_lut, s_tiles);
 }
@@ -463,7 +465,13 @@ enum { MARCH_PAIR = 0, MARCH_REFBLUR = 1, MARCH_EMIT = 2 };
 // the pixel of this lane's column in the next output row, plus a prefetch queue (the values are
 // loaded RB_AHEAD steps before the step that consumes them; HBM latency under load is several
 // row steps).
-constexpr int RB_AHEAD = 4;
+#ifndef MARCH_RB_AHEAD
+#define MARCH_RB_AHEAD 6   // round 4: 4 / 6 / 8 = 0.1621 / 0.1597 / 0.1636 ms per cached 4K pass (profiles/r04_refblur_ab.log)
+#endif
+#ifndef MARCH_NT_CACHED
+#define MARCH_NT_CACHED 0   // 1: streaming (nontemporal) loads of the cached reference planes, read once per pass
+#endif
+constexpr int RB_AHEAD = MARCH_RB_AHEAD;
 struct MarchRefBlur {
     float* s11;
     int pitch;       // elements per row
@@ -522,13 +530,17 @@ __device__ __forceinline__ MarchCursor march_cursor(const void* base, int w, int
 // the load is unconditional: every row issues the same number of loads and the compiler's
 // s_waitcnt vmcnt(N) can count them -- a conditional load made it fall back to vmcnt(0), which
 // shortened the prefetch distance to one row).
-template <bool U8>
+template <bool U8, bool NT = false>
 __device__ __forceinline__ void march_load(uint32_t (&raw)[3], const MarchCursor& c, int row) {
     const uint8_t* p = c.base + (size_t)(uint32_t)row * (uint32_t)c.pitch;
     if (U8) {
         uint32_t d;
         __builtin_memcpy(&d, p + c.off, 4);
         raw[0] = d;
+    } else if (NT) {
+        raw[0] = __builtin_nontemporal_load((const uint32_t*)(p + c.off));
+        raw[1] = __builtin_nontemporal_load((const uint32_t*)(p + c.plane + c.off));
+        raw[2] = __builtin_nontemporal_load((const uint32_t*)(p + 2 * c.plane + c.off));
     } else {
         raw[0] = *(const uint32_t*)(p + c.off);
         raw[1] = *(const uint32_t*)(p + c.plane + c.off);
@@ -595,7 +607,7 @@ __device__ __forceinline__ void march_convert_rows(f2 (*ring)[3][MRW], const flo
 #define MARCH_LOAD(J)                                                      \
     {                                                                      \
         const int lrow_ = min(max(load_row, 0), h - 1); /* uniform */      \
-        if (CACHED) march_load<false>(raw0[J], c0, lrow_);                 \
+        if (CACHED) march_load<false, MARCH_NT_CACHED != 0>(raw0[J], c0, lrow_); \
         else march_load<U8>(raw0[J], c0, lrow_);                           \
         if (TWO) march_load<U8>(raw1[J], c1, lrow_);                       \
         ++load_row;                                                        \
@@ -761,7 +773,7 @@ __device__ __forceinline__ void march_v(const lds_vu64* rp, float (&win)[5][9], 
         // consume the value loaded RB_AHEAD steps ago, then load the row RB_AHEAD steps ahead
         c_s11 = rb.ps11[P];
         if (t >= 8 - RB_AHEAD && rb.rows_left > 0) {  // uniform: that output row exists
-            rb.ps11[(P + RB_AHEAD) % 9] = ok ? *rb.s11 : 0.0f;
+            rb.ps11[(P + RB_AHEAD) % 9] = ok ? (MARCH_NT_CACHED ? __builtin_nontemporal_load(rb.s11) : *rb.s11) : 0.0f;
             rb.s11 += rb.pitch;
             --rb.rows_left;
         }

@@ -60,6 +60,12 @@ struct RgPlan {
     double* part[kNumScales];     // [18 statistics][vgroups]
     float* emit[kNumScales];      // k_rg_v_emit target [channel][plane of the pass][n]; null = skip the scale
     float* dump;                  // one row of floats that absorbs the stores of rows outside the image
+    // persistent scheduling (k_rg_h, k_rg_v): jobs in decreasing length (largest scale first), handed
+    // out through cursors in device memory that the conversion launch in front of them zeroes
+    int hjob_end[kNumScales];     // exclusive end of each scale's jobs of the horizontal pass
+    int hjobs, hlong;             // all of them / the first `hlong` form the queue of the long class
+    int vjobs;                    // jobs of the vertical pass = vblk_end[nscales - 1]
+    unsigned* q;                  // [0] long-queue cursor, [1] filler-queue cursor (k_rg_h), [2] k_rg_v's
 };
 
 // ---- the recursion --------------------------------------------------------------------------------
@@ -130,6 +136,9 @@ typedef float rg_f4u __attribute__((ext_vector_type(4), aligned(4)));  // a row 
 #endif
 #ifndef RG_EXP_H_SAMETILE
 #define RG_EXP_H_SAMETILE 0  // horizontal pass loading tile 0 over and over (cache-fed)
+#endif
+#ifndef RG_EXP_H_CLASS
+#define RG_EXP_H_CLASS 0     // 1: only the long class works (filler waves exit), 2: only the filler class
 #endif
 #ifndef RG_EXP_V_SAMEROWS
 #define RG_EXP_V_SAMEROWS 0  // vertical pass loading rows 0-9 of every plane over and over (cache-fed)
@@ -221,25 +230,30 @@ __device__ __forceinline__ void rg_h_store(const RgLine& L, const RgRing& tout, 
 }
 
 template <bool FMA, int OPK, bool EDGE>
-__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout, float* dump,
+__device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin, RgRing& tout, float* dump,
                                           rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
     const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
     __builtin_amdgcn_wave_barrier();
+    // the plane the recursion runs over is formed HERE, once per element, by the lane that staged
+    // it (a product is one fp32 multiply, rounded before the blur as published -- the same value
+    // whichever lane forms it); the three section lanes of a line then read it ready-made
 #pragma unroll
     for (int i = 0; i < RG_TR; ++i) {
-        *reinterpret_cast<rg_f4*>(&tin_a[4 * i + rr][4 * cc]) = ra[i];
-        if (OPK == 2) *reinterpret_cast<rg_f4*>(&tin_b[4 * i + rr][4 * cc]) = rb[i];
+        rg_f4 v = OPK == 0 ? ra[i] : OPK == 1 ? ra[i] * ra[i] : ra[i] * rb[i];
+        if (EDGE) {  // zeros outside the row: the published padding
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = T * RG_TW + 4 * cc + e < L.w ? v[e] : 0.0f;
+        }
+        *reinterpret_cast<rg_f4*>(&tin[4 * i + rr][4 * cc]) = v;
     }
     rg_h_fetch<OPK>(L, ra, rb, T + 1);  // lands under this tile's 64 steps
     __builtin_amdgcn_wave_barrier();
     // 16 columns at a time; the LDS reads of the next 16 are issued before the steps of these 16
-    // (an LDS read takes ~100+ cycles to land; a lone wave per SIMD has nothing else to run)
-    rg_f4 va[2][RG_HT / 4], vb[2][RG_HT / 4];
-#define RG_H_READ(S)                                                                                       \
-    _Pragma("unroll") for (int v = 0; v < RG_HT / 4; ++v) {                                                \
-        va[(S) & 1][v] = *reinterpret_cast<const rg_f4*>(&tin_a[L.line][RG_HT * (S) + 4 * v]);             \
-        if (OPK == 2) vb[(S) & 1][v] = *reinterpret_cast<const rg_f4*>(&tin_b[L.line][RG_HT * (S) + 4 * v]); \
-    }
+    // (an LDS read takes ~100+ cycles to land)
+    rg_f4 va[2][RG_HT / 4];
+#define RG_H_READ(S)                                                                           \
+    _Pragma("unroll") for (int v = 0; v < RG_HT / 4; ++v)                                      \
+        va[(S) & 1][v] = *reinterpret_cast<const rg_f4*>(&tin[L.line][RG_HT * (S) + 4 * v]);
     RG_H_READ(0)
 #pragma unroll
     for (int s = 0; s < RG_TW / RG_HT; ++s) {
@@ -252,13 +266,7 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
 #pragma unroll
         for (int v = 0; v < RG_HT / 4; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                c[4 * v + e] = OPK == 0 ? va[s & 1][v][e] : OPK == 1 ? va[s & 1][v][e] * va[s & 1][v][e]
-                                                                       : va[s & 1][v][e] * vb[s & 1][v][e];
-        if (EDGE) {
-#pragma unroll
-            for (int mm = 0; mm < RG_HT; ++mm) c[mm] = T * RG_TW + RG_HT * s + mm < L.w ? c[mm] : 0.0f;
-        }
+            for (int e = 0; e < 4; ++e) c[4 * v + e] = va[s & 1][v][e];
         float o[RG_HT];
 #pragma unroll
         for (int mm = 0; mm < RG_HT; ++mm) {
@@ -267,8 +275,7 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
         }
         // output columns 64 T - 4 + 16 s ..: ring position = column mod 128.  Every lane stores (no
         // branch around LDS traffic in the middle of the tile): the lanes that do not hold the
-        // line's output write their 16 bytes into a dump row nobody reads (one per workgroup: three
-        // workgroups per CU need the LDS to stay below 53.3 KB).
+        // line's output write their 16 bytes into a dump row nobody reads.
 #pragma unroll
         for (int v = 0; v < RG_HT / 4; ++v) {
             const int col = (T * RG_TW - (RG_N - 1) + RG_HT * s + 4 * v) & (RG_OW - 1);
@@ -282,7 +289,7 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin_a, RgTile& tin_
 }
 
 template <bool FMA, int OPK>
-__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_b, RgRing& tout, float* dump) {
+__device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin, RgRing& tout, float* dump) {
     const int w = L.w;
     const int ntiles = (w + (RG_N - 1) + RG_TW - 1) / RG_TW;  // steps run to m = w + 3
     // tiles 1 .. nmain - 1 lie inside the row and complete a segment that does (64 (T + 1) <= w)
@@ -292,12 +299,12 @@ __device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin_a, RgTile& tin_
     for (int k = 0; k < RG_HT; ++k) L.cur[1][k] = 0.0f;  // columns -16 .. -1
     L.p1 = L.p2 = 0.0f;
     rg_h_fetch<OPK>(L, ra, rb, 0);
-    rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, dump, ra, rb, 0);
+    rg_h_tile<FMA, OPK, true>(L, tin, tout, dump, ra, rb, 0);
     int T = 1;
 #pragma unroll 1
-    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin_a, tin_b, tout, dump, ra, rb, T);
+    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin, tout, dump, ra, rb, T);
 #pragma unroll 1
-    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin_a, tin_b, tout, dump, ra, rb, T);
+    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin, tout, dump, ra, rb, T);
     __builtin_amdgcn_wave_barrier();
     rg_h_store<true>(L, tout, ntiles - 1);  // the row's last columns (w - 1 <= 64 (ntiles - 1) + 59)
 }
@@ -308,11 +315,107 @@ __host__ __device__ __forceinline__ int rg_plane15(bool ref, int ch, int kind) {
 }
 
 // Horizontal pass.  REF: the planes {x, x*x} of the reference (once per search); otherwise
-// {y, y*y, x*y}.  grid = sum over scales of 3 channels x ceil(h / 20) workgroups of NK waves.
+// {y, y*y, x*y}.  grid = sum over scales of 3 channels x ceil(h / 20) workgroups of NK waves, one wave
+// per plane, each staging and recursing its own tiles.
+//
+// What bounds it (round 4, profiles/r04_rg_chain_vs_bytes.log, 4K pass): with every HBM access taken
+// away the launch takes 139 us (a wave alone on a SIMD needs 26 ns per step, 101 us for a 3,840-step
+// row; some SIMDs hold two full-resolution waves), with only its loads or only its stores coming from
+// HBM 144-152 us, with both 173-177 us: 0.70 GB of interleaved reads and writes at 4.0 TB/s, which is
+// what a mixed read + write stream reaches on this chip (the conversion kernel, 84 % writes: 4.4 TB/s).
+// A persistent form that gives every full-resolution chain a SIMD of its own (RG_H_PERSISTENT = 1:
+// one workgroup of eight waves per CU, jobs handed out longest first through two cursors, the class
+// of a wave decided by the SIMD it finds itself on) has the same 137 us without HBM and 206-222 us
+// with it -- more row streams in flight, the long chains exposed to the memory latency once their
+// partner wave has finished -- so it stays an A/B build; the bytes of the h -> v round trip are the
+// bound, not the placement.
+#ifndef RG_H_PERSISTENT
+#define RG_H_PERSISTENT 0
+#endif
+constexpr int RG_HW = 8;  // waves per workgroup of the persistent form
+template <bool REF>
+__device__ __forceinline__ int rg_h_pull(const RgPlan& p, bool long_first) {
+    int job = -1;
+    if ((threadIdx.x & 63) == 0) {
+        const int nq[2] = {p.hlong, p.hjobs - p.hlong};
+        const int a = long_first ? 0 : 1;
+        int idx = (int)atomicAdd(p.q + a, 1u);
+        if (idx < nq[a]) job = a == 0 ? idx : p.hlong + idx;
+        else if (!RG_EXP_H_CLASS) {
+            idx = (int)atomicAdd(p.q + (1 - a), 1u);
+            if (idx < nq[1 - a]) job = a == 0 ? p.hlong + idx : idx;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(job);
+}
+
+template <bool FMA, bool REF>
+__global__ __launch_bounds__(64 * RG_HW) void k_rg_h_persistent(RgPlan p) {
+    constexpr int NK = REF ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) RgTile s_in[RG_HW];
+    __shared__ __attribute__((aligned(16))) RgRing s_o[RG_HW];
+    __shared__ __attribute__((aligned(16))) float s_dump[RG_OW];
+    __shared__ int s_on_simd[4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // class of this wave: the FIRST wave of the workgroup on each SIMD is of the long class, whatever
+    // order the dispatcher placed the eight waves in (HW_ID bits 5:4 = the SIMD the wave runs on)
+    if (threadIdx.x < 4) s_on_simd[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    int arrival = 0;
+    if (lane == 0) arrival = atomicAdd(&s_on_simd[(hw_id >> 4) & 3u], 1);
+    const bool long_class = __builtin_amdgcn_readfirstlane(arrival) == 0;
+    (void)wave;
+    if (RG_EXP_H_CLASS == 1 && !long_class) return;
+    if (RG_EXP_H_CLASS == 2 && long_class) return;
+    RgLine L;
+    // lane -> (DPP row, line, section); lane 15 of a row shadows line 4 / section 5 and holds nothing
+    const int l16 = lane & 15;
+    const int sec = l16 < 15 ? l16 / 5 : 2;
+    L.line = (lane >> 4) * 5 + (l16 < 15 ? l16 - 5 * sec : 4);
+    L.holds_out = l16 >= 10 && l16 < 15;
+    L.n2 = c_k.rg_n2[sec];
+    L.d1 = c_k.rg_d1[sec];
+#pragma unroll 1
+    for (;;) {
+        const int job = rg_h_pull<REF>(p, long_class);
+        if (job < 0) break;
+        int sc = 0, first = 0;
+#pragma unroll
+        for (int s = 0; s < kNumScales - 1; ++s)
+            if (s + 1 < p.nscales && job >= p.hjob_end[s]) {
+                sc = s + 1;
+                first = p.hjob_end[s];
+            }
+        // jobs of a scale: row group, then channel, then plane -- neighbours share their inputs
+        const int local = job - first;
+        const int rgrp = local / (3 * NK), ch = local % (3 * NK) / NK, kind = local % NK;
+        const int w = p.w[sc], h = p.h[sc];
+        const size_t n = (size_t)w * h;
+        L.w = w;
+        // rows of the cooperative 16-byte accesses; rows behind the image shadow its last row (their
+        // lines compute and store that row's values once more)
+#pragma unroll
+        for (int i = 0; i < RG_TR; ++i)
+            L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)w + 4u * (uint32_t)(lane & 15);
+        const float* xa = p.xa[sc] + ch * n;
+        const float* xb = REF ? xa : p.xb[sc] + ch * n;
+        L.gout = p.hbuf[sc] + (size_t)(ch * NK + kind) * n;
+        // REF: x, x*x.  pass: y, y*y, x*y
+        L.ga = kind == 2 ? xa : xb;
+        L.gb = xb;
+        if (kind == 0) rg_h_line<FMA, 0>(L, s_in[wave], s_o[wave], s_dump);
+        else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[wave], s_o[wave], s_dump);
+        else rg_h_line<FMA, 2>(L, s_in[wave], s_o[wave], s_dump);
+    }
+}
+
 template <bool FMA, bool REF>
 __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (capped at 168 VGPRs for 3 waves per SIMD it spills and is slower)
     constexpr int NK = REF ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) RgTile s_in[REF ? 2 : 4];
+    __shared__ __attribute__((aligned(16))) RgTile s_in[NK];
     __shared__ __attribute__((aligned(16))) RgRing s_o[NK];
     __shared__ __attribute__((aligned(16))) float s_dump[RG_OW];
     int sc = 0, first = 0;
@@ -348,9 +451,9 @@ __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (cappe
     // REF: x, x*x.  pass: y, y*y, x*y
     L.ga = kind == 2 ? xa : xb;
     L.gb = xb;
-    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_in[0], s_o[0], s_dump);
-    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_in[1], s_o[1], s_dump);
-    else rg_h_line<FMA, 2>(L, s_in[REF ? 0 : 2], s_in[REF ? 1 : 3], s_o[NK - 1], s_dump);
+    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_o[0], s_dump);
+    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_o[1], s_dump);
+    else rg_h_line<FMA, 2>(L, s_in[NK - 1], s_o[NK - 1], s_dump);
 }
 
 // ---- vertical pass (+ maps) -----------------------------------------------------------------------
@@ -383,7 +486,10 @@ __device__ __forceinline__ void rg_maps_pixel(float mu1, float mu2, float s11, f
 // steps), lanes right of the image shadow its last column, and the batch count is rounded up to
 // the queue depth (the batches behind the image produce nothing that is kept).  `emit(b, o)`
 // receives the ten outputs of batch b: rows 10 b - 4 .. 10 b + 5.
-constexpr int RG_PF = 4;
+#ifndef RG_PF_DEPTH
+#define RG_PF_DEPTH 6   // 4 -> 6 with one workgroup per CU (round 4): 0.388 -> 0.375 ms per cached 4K pass; 8: 0.378
+#endif
+constexpr int RG_PF = RG_PF_DEPTH;  // queue slots: RG_PF - 1 batches in flight under the one consumed
 __device__ __forceinline__ int rg_v_batches(int h) {
     return ((h + (RG_N - 1) + RG_VB - 1) / RG_VB + RG_PF - 1) / RG_PF * RG_PF;  // step m = right-hand row, to h + 3
 }
@@ -403,16 +509,15 @@ __device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w,
                            : in[(size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * w];
 #pragma unroll
     for (int j = 0; j < RG_VB; ++j) q[RG_PF - 1][j] = 0.f;  // batch -1: rows -10 .. -1
-    RG_V_LOAD(0, 0)
-    RG_V_LOAD(1, 1)
-    RG_V_LOAD(2, 2)
+#pragma unroll
+    for (int k = 0; k < RG_PF - 1; ++k) { RG_V_LOAD(k, k) }
 #pragma unroll 1
     for (int b0 = 0; b0 < nb; b0 += RG_PF) {
 #pragma unroll
         for (int u = 0; u < RG_PF; ++u) {
             const int b = b0 + u;
-            // the slot of batch b + 3 is the one batch b - 1 (this batch's left-hand inputs) sits
-            // in, so its loads are issued AFTER the steps
+            // the slot of batch b + RG_PF - 1 is the one batch b - 1 (this batch's left-hand inputs)
+            // sits in, so its loads are issued AFTER the steps
             float (&right)[RG_VB] = q[u];
             const float (&left)[RG_VB] = q[(u + RG_PF - 1) % RG_PF];
             if (b * RG_VB + RG_VB > h) {  // uniform: the image ends inside or before this batch
@@ -422,7 +527,7 @@ __device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w,
             float o[RG_VB];
 #pragma unroll
             for (int j = 0; j < RG_VB; ++j) o[j] = rg_step<FMA>(st, left[j], right[j], n2, d1);
-            RG_V_LOAD(b + 3, (u + 3) % RG_PF)
+            RG_V_LOAD(b + RG_PF - 1, (u + RG_PF - 1) % RG_PF)
             emit(b, o);
         }
     }
@@ -464,47 +569,64 @@ __global__ __launch_bounds__(64 * NK) void k_rg_v_emit(RgPlan p) {
 
 // Vertical pass of a pass's planes + maps.  Waves 0-2 recurse {y, y*y, x*y} into a double-buffered
 // LDS tile of ten rows, waves 3-7 turn two of those rows each, with the cached mu1 / s11 and the two
-// frames' XYB values, into the six sums.  grid = sum over scales of 3 channels x ceil(w / 64).
+// frames' XYB values, into the six sums.  A JOB is one channel of 64 columns of one scale (a chain of
+// h steps); round 4: PERSISTENT like k_rg_h -- one workgroup per CU (launched with RG_V_PAD_BYTES
+// of unused dynamic LDS, past half a CU's), the jobs of all scales handed out longest first through a cursor.  Measured before the change
+// (profiles/r04_rg_chain_vs_bytes.log): capping the round-3 launch at one workgroup per CU took it from
+// 193 to 170 us -- with two per CU the dispatcher doubles up full-resolution column groups on some CUs
+// while others run the small scales, and a CU with two of them issues at half the rate per chain.
+constexpr int RG_V_PAD_BYTES = 70 * 1024;  // dynamic LDS of the launch, never touched: pushes the workgroup past 80 KB
+
 template <bool FMA>
 __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
     constexpr int NK = 3;
     __shared__ float s_out[2][NK][RG_VB][RG_VW];
     __shared__ double s_part[RG_MAPS_WAVES][6];
-    int sc = 0, first = 0;
-#pragma unroll
-    for (int s = 0; s < kNumScales - 1; ++s)
-        if (s + 1 < p.nscales && (int)blockIdx.x >= p.vblk_end[s]) {
-            sc = s + 1;
-            first = p.vblk_end[s];
-        }
-    const int blk = (int)blockIdx.x - first;
-    const int ch = blk % 3, cg = RG_EXP_V_REVERSE ? p.vgroups[sc] - 1 - blk / 3 : blk / 3;
+    __shared__ int s_job;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int w = p.w[sc], h = p.h[sc];
-    const size_t n = (size_t)w * h;
-    const int x = cg * RG_VW + lane;
-    const bool ok = x < w;
-    const int xc = min(x, w - 1);
-    const int nb = rg_v_batches(h);
-
-    if (wave < NK) {
-        const int kind = wave;
-        const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
-        rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
+#pragma unroll 1
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int j = (int)atomicAdd(p.q + 2, 1u);
+            s_job = j < p.vjobs ? j : -1;
+        }
+        __syncthreads();
+        const int job = __builtin_amdgcn_readfirstlane(s_job);
+        if (job < 0) break;
+        int sc = 0, first = 0;
 #pragma unroll
-            for (int j = 0; j < RG_VB; ++j) s_out[b & 1][kind][j][lane] = o[j];
-            __syncthreads();  // batch b is in the tile
-        });
-    } else {
-        // maps: this wave's two rows of every batch; the same barriers as the recursion waves
-        const int j0 = 2 * (wave - NK);
-        const float* g_mu1 = p.cache[sc] + (size_t)(2 * ch) * n + xc;
-        const float* g_s11 = g_mu1 + n;
-        const float* g_r1 = p.xa[sc] + (size_t)ch * n + xc;
-        const float* g_r2 = p.xb[sc] + (size_t)ch * n + xc;
-        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        float g[RG_PF][2][4];
+        for (int s = 0; s < kNumScales - 1; ++s)
+            if (s + 1 < p.nscales && job >= p.vblk_end[s]) {
+                sc = s + 1;
+                first = p.vblk_end[s];
+            }
+        const int blk = job - first;
+        const int ch = blk % 3, cg = RG_EXP_V_REVERSE ? p.vgroups[sc] - 1 - blk / 3 : blk / 3;
+        const int w = p.w[sc], h = p.h[sc];
+        const size_t n = (size_t)w * h;
+        const int x = cg * RG_VW + lane;
+        const bool ok = x < w;
+        const int xc = min(x, w - 1);
+        const int nb = rg_v_batches(h);
+
+        if (wave < NK) {
+            const int kind = wave;
+            const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
+            rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
+#pragma unroll
+                for (int j = 0; j < RG_VB; ++j) s_out[b & 1][kind][j][lane] = o[j];
+                __syncthreads();  // batch b is in the tile
+            });
+        } else {
+            // maps: this wave's two rows of every batch; the same barriers as the recursion waves
+            const int j0 = 2 * (wave - NK);
+            const float* g_mu1 = p.cache[sc] + (size_t)(2 * ch) * n + xc;
+            const float* g_s11 = g_mu1 + n;
+            const float* g_r1 = p.xa[sc] + (size_t)ch * n + xc;
+            const float* g_r2 = p.xb[sc] + (size_t)ch * n + xc;
+            double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            float g[RG_PF][2][4];
 #define RG_M_LOAD(B, SLOT)                                                     \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                         \
         const int r_ = (RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j0 + jj - (RG_N - 1); \
@@ -514,49 +636,51 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
         g[SLOT][jj][2] = RG_NT_LD ? __builtin_nontemporal_load(g_r1 + o_) : g_r1[o_];   \
         g[SLOT][jj][3] = RG_NT_LD ? __builtin_nontemporal_load(g_r2 + o_) : g_r2[o_];   \
     }
-        RG_M_LOAD(0, 0)
-        RG_M_LOAD(1, 1)
-        RG_M_LOAD(2, 2)
+#pragma unroll
+            for (int k = 0; k < RG_PF - 1; ++k) { RG_M_LOAD(k, k) }
 #pragma unroll 1
-        for (int b0 = 0; b0 < nb; b0 += RG_PF) {
+            for (int b0 = 0; b0 < nb; b0 += RG_PF) {
 #pragma unroll
-            for (int u = 0; u < RG_PF; ++u) {
-                const int b = b0 + u;
-                RG_M_LOAD(b + 3, (u + 3) % RG_PF)
-                __syncthreads();  // batch b is in the tile
+                for (int u = 0; u < RG_PF; ++u) {
+                    const int b = b0 + u;
+                    RG_M_LOAD(b + RG_PF - 1, (u + RG_PF - 1) % RG_PF)
+                    __syncthreads();  // batch b is in the tile
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int r = b * RG_VB + j0 + jj - (RG_N - 1);
-                    if (r >= 0 && r < h) {  // uniform
-                        const float mu2 = s_out[b & 1][0][j0 + jj][lane];
-                        const float s22 = s_out[b & 1][1][j0 + jj][lane];
-                        const float s12 = s_out[b & 1][2][j0 + jj][lane];
-                        double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                        rg_maps_pixel(g[u][jj][0], mu2, g[u][jj][1], s22, s12, g[u][jj][2], g[u][jj][3], z);
-                        if (ok) {
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int r = b * RG_VB + j0 + jj - (RG_N - 1);
+                        if (r >= 0 && r < h) {  // uniform
+                            const float mu2 = s_out[b & 1][0][j0 + jj][lane];
+                            const float s22 = s_out[b & 1][1][j0 + jj][lane];
+                            const float s12 = s_out[b & 1][2][j0 + jj][lane];
+                            double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                            rg_maps_pixel(g[u][jj][0], mu2, g[u][jj][1], s22, s12, g[u][jj][2], g[u][jj][3], z);
+                            if (ok) {
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) acc[k] += z[k];
+                                for (int k = 0; k < 6; ++k) acc[k] += z[k];
+                            }
                         }
                     }
                 }
             }
-        }
 #undef RG_M_LOAD
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double sum = wave_sum(acc[k]);
-            if (lane == 0) s_part[wave - NK][k] = sum;
+            for (int k = 0; k < 6; ++k) {
+                const double sum = wave_sum(acc[k]);
+                if (lane == 0) s_part[wave - NK][k] = sum;
+            }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int k = threadIdx.x;
-        double sum = s_part[0][k];
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int k = threadIdx.x;
+            double sum = s_part[0][k];
 #pragma unroll
-        for (int m = 1; m < RG_MAPS_WAVES; ++m) sum += s_part[m][k];
-        // statistic index as k_finalize reads it: 0..5 ssim (c*2 + n), 6..17 edge (c*4 + j)
-        const int stat = k < 2 ? ch * 2 + k : 6 + ch * 4 + (k - 2);
-        p.part[sc][(size_t)stat * p.vgroups[sc] + cg] = sum;
+            for (int m = 1; m < RG_MAPS_WAVES; ++m) sum += s_part[m][k];
+            // statistic index as k_finalize reads it: 0..5 ssim (c*2 + n), 6..17 edge (c*4 + j)
+            const int stat = k < 2 ? ch * 2 + k : 6 + ch * 4 + (k - 2);
+            p.part[sc][(size_t)stat * p.vgroups[sc] + cg] = sum;
+        }
+        // the next job's first barrier (behind its pull) orders these reads of s_part / s_job before
+        // anything overwrites them
     }
 }
 
