@@ -161,13 +161,17 @@ def pack_records(results: Sequence[ImageResult]) -> np.ndarray:
     return rec
 
 
-def gather_records(local: np.ndarray, n_total: int, device=None, per_rank: Optional[int] = None) -> np.ndarray:
+def gather_records(local: np.ndarray, n_total: int, device=None, per_rank: Optional[int] = None,
+                   always: bool = False) -> np.ndarray:
     """All-gather the (n_local, 8) float64 record arrays of all ranks -> (n_total, 8) sorted by
     image index.  One collective; works on gloo (CPU tensors) and nccl = RCCL (GPU tensors).
-    `per_rank`: rows of the fixed-size buffer every rank contributes (the largest shard)."""
+    `per_rank`: rows of the fixed-size buffer every rank contributes (the largest shard).
+    `always`: run the collective even in a process group of one rank (a one-GPU box can then push
+    the device-tensor all_gather through RCCL: tests/test_gpu_batch.py; OAVIF_GATHER_ALWAYS=1 for
+    the batch driver) instead of returning the local records directly."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always):
         return local[np.argsort(local[:, 0])] if len(local) else local
     world = dist.get_world_size()
     if per_rank is None:
@@ -269,7 +273,7 @@ def summarize(results: Sequence[ImageResult], wall_s: float, world: int = 1) -> 
 
 def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tuple], rank: int = 0,
               world: int = 1, gather_device=None, log=None, workers: int = 1,
-              deal: Optional[List[List[int]]] = None) -> List[ImageResult]:
+              deal: Optional[List[List[int]]] = None, gather_always: bool = False) -> List[ImageResult]:
     """Process this rank's shard with `encode_fn(index, path) -> (q, score, passes, final_bytes)`
     and return the gathered, index-sorted results of ALL ranks.  `deal`: the index list of every
     rank (default: deal_largest_first over the files' sizes).
@@ -310,7 +314,7 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
     else:
         local = [one(i) for i in mine]
     rec = gather_records(pack_records(local), len(image_files), gather_device,
-                         per_rank=max(len(d) for d in deal))
+                         per_rank=max(len(d) for d in deal), always=gather_always)
     names = [p.name for p in image_files]
     results = records_to_results(rec, names)
     for r in results:  # error strings stay on the rank that produced them; keep local ones
@@ -416,7 +420,15 @@ def main(argv=None) -> int:
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # OAVIF_GATHER_ALWAYS=1: a single rank still opens its process group and sends its records through
+    # the collective (what a one-GPU box can exercise of the RCCL path: the same call on device tensors)
+    gather_always = os.environ.get("OAVIF_GATHER_ALWAYS", "") == "1"
+    if world == 1 and gather_always:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or gather_always:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -452,8 +464,8 @@ def main(argv=None) -> int:
         dist.barrier()
     t0 = time.perf_counter()
     results = run_batch(files, encode_fn, rank, world,
-                        gather_device=torch.device("cuda", local_rank) if world > 1 and backend == "nccl" else None,
-                        log=lambda s: print(s, file=sys.stderr), workers=args.workers)
+                        gather_device=torch.device("cuda", local_rank) if (world > 1 or gather_always) and backend == "nccl" else None,
+                        log=lambda s: print(s, file=sys.stderr), workers=args.workers, gather_always=gather_always)
     wall = time.perf_counter() - t0
     if not args.keep:
         for i in deal_largest_first([_size_or_zero(p) for p in files], world)[rank]:
@@ -472,7 +484,7 @@ def main(argv=None) -> int:
         print(f"\nResults written to {args.output_csv}")
     for sc in all_scorers:
         sc.close()
-    if world > 1:
+    if world > 1 or gather_always:
         dist.destroy_process_group()
     return 0
 

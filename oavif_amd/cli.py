@@ -34,15 +34,24 @@ class CliError(Exception):
 
 
 def blur_from_env():
-    """OAVIF_SSIMU2_BLUR=recursive selects the published recursive Gaussian (ssimu2_ctx_set_blur,
-    include/ssimu2_hip.h) for this run; unset / "fir" = the default fused kernels.  Read by the
-    host side only: the C library itself reads no environment."""
-    v = os.environ.get("OAVIF_SSIMU2_BLUR", "").strip().lower()
-    if v in ("", "fir"):
-        return None
+    """The blur of the SEARCH PATH (this CLI, the batch driver; the Zig shim's `blur` says the same):
+    the published recursive Gaussian, `recursive`, unless OAVIF_SSIMU2_BLUR says `fir` or `recursive_fma`.
+
+    Why the recursion is the default here since round 4: fssimu2's source is not available, so which fp32
+    evaluation of the blur it uses is unknown (parity unpinned); what IS known is that the published
+    SSIMULACRA2 code blurs recursively, that the FIR form differs from it by a median 0.5 / up to 2.4
+    points at 3840x2160 and ends 8 of 24 4K searches on another quantizer (profiles/
+    r04_4k_search_both_modes.json), and that following the published arithmetic costs 0.38 instead of
+    0.16 ms of a ~140 ms pass.  With the cost at 0.2 % the search follows the published order; `fir` stays
+    the throughput mode (what bench.py's `value` measures, what a context defaults to at the C ABI).
+    tests/golden/pin_kit + scripts/pin_blur_mode.py settle the question for anyone who can run fssimu2.
+    Read by the host side only: the C library itself reads no environment."""
     from . import _lib
-    if v in ("recursive", "iir"):
+    v = os.environ.get("OAVIF_SSIMU2_BLUR", "").strip().lower()
+    if v in ("", "recursive", "iir"):
         return _lib.BLUR_RECURSIVE
+    if v == "fir":
+        return None
     if v in ("recursive_fma", "recursive-fma", "iir_fma"):
         return _lib.BLUR_RECURSIVE_FMA
     raise CliError(f"OAVIF_SSIMU2_BLUR={v!r}: expected 'fir', 'recursive' or 'recursive_fma'")

@@ -52,19 +52,24 @@ pub var device: c_int = 0;
 pub var cache_reference: bool = true;
 
 /// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur):
-///   `.fir`        the THROUGHPUT mode (default; what the benchmarks measure): the fused 9-tap
-///                 kernels, 0.16 ms per 4K pass;
-///   `.recursive`  the CONSERVATIVE-PARITY mode: the published recursive Gaussian operation for
-///                 operation (libjxl's order; planes bit-identical to the CPU checker's), 0.4 ms per
-///                 4K pass with the reference cached -- still 0.3 % of a pass's encode + decode.
-/// The two differ by the recursion's own rounding noise (median 0.02 points on small frames, 0.5
-/// at 4K, where a third of the searches then end on another quantizer); which of them fssimu2
-/// 0.1.1 agrees with could not be checked where this shim was written.  A maintainer who can run
-/// fssimu2 should score a few 4K pairs in both modes once and set the one that matches; if in
-/// doubt for a search (where the encode dominates anyway) `.recursive` follows the published
-/// arithmetic.  Set before the first call.
+///   `.recursive`  DEFAULT of this shim (the search path) since round 4: the published recursive
+///                 Gaussian operation for operation (libjxl's scalar order; planes bit-identical to the
+///                 CPU checker's), 0.38 ms per 4K pass with the reference cached -- 0.3 % of a pass's
+///                 encode + decode;
+///   `.recursive_fma`  the same recursion with its multiply-subtract fused (what a compiler targeting
+///                 an FMA unit makes of the published code);
+///   `.fir`        the THROUGHPUT mode (what the benchmarks measure, what a context starts in at the
+///                 C ABI): the recursion's exact 9-tap impulse response in fused kernels, 0.16 ms.
+/// Why `.recursive`: fssimu2's source was not available where this shim was written, so which fp32
+/// evaluation of the blur it follows is unknown.  The modes differ by the recursion's own rounding
+/// noise -- median 0.02 points on small frames, 0.5 at 4K, where 8 of 24 searches then end on another
+/// quantizer -- and the published SSIMULACRA2 code is the recursion; with the scorer at 0.3 % of a
+/// pass either way, the search follows the published arithmetic.  A maintainer who can run fssimu2
+/// settles it in minutes: tests/golden/pin_kit holds pairs on which the three modes are 0.1 to 3.8
+/// points apart with the score of each, scripts/pin_blur_mode.py takes fssimu2's scores of the same
+/// files and names the mode that matches within +-0.01 (INTEGRATION.md 2e).  Set before the first call.
 pub const Blur = enum(c_int) { fir = 0, recursive = 1, recursive_fma = 2 };
-pub var blur: Blur = .fir;
+pub var blur: Blur = .recursive;
 
 var g_ctx: ?*Ctx = null;
 var g_ref_ptr: ?[*]const u8 = null;

@@ -37,6 +37,7 @@ def main():
     results = batch.run_batch(files, scripted_encode, rank, world, workers=int(os.environ.get('BATCH_WORKERS', '1')))
     deal = batch.deal_largest_first([p.stat().st_size for p in files], world)
     json.dump({"rank": rank, "affinity": sorted(os.sched_getaffinity(0)), "indices": deal[rank],
+               "gather_rows_per_rank": max(len(d) for d in deal),
                "bytes": sum(files[i].stat().st_size for i in deal[rank])},
               open(f"{out_json}.rank{rank}", "w"))
     if rank == 0:

@@ -178,10 +178,11 @@ def test_early_error_exit_after_prefetch_does_not_hang(tmp_path):
 
 def test_blur_mode_selector_from_environment(monkeypatch):
     """OAVIF_SSIMU2_BLUR (host side only; the C library reads no environment): fir / recursive /
-    recursive_fma map to ssimu2_ctx_set_blur's modes, anything else is refused."""
+    recursive_fma map to ssimu2_ctx_set_blur's modes, anything else is refused.  Unset = the search
+    path's default since round 4: the published recursion."""
     from oavif_amd import _lib, cli
     monkeypatch.delenv("OAVIF_SSIMU2_BLUR", raising=False)
-    assert cli.blur_from_env() is None
+    assert cli.blur_from_env() == _lib.BLUR_RECURSIVE
     for text, mode in (("fir", None), ("recursive", _lib.BLUR_RECURSIVE), ("IIR", _lib.BLUR_RECURSIVE),
                        ("recursive_fma", _lib.BLUR_RECURSIVE_FMA), (" recursive-fma ", _lib.BLUR_RECURSIVE_FMA)):
         monkeypatch.setenv("OAVIF_SSIMU2_BLUR", text)

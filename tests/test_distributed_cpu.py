@@ -226,6 +226,35 @@ def test_world2_placement_csv_equal_loads_even_affinity_disjoint(varied_dir, tmp
         assert r[0]["affinity"] and r[1]["affinity"] and not set(r[0]["affinity"]) & set(r[1]["affinity"])
 
 
+def test_world8_gloo_256_images_of_uneven_sizes(tmp_path):
+    """BASELINE configs[3]'s shape rehearsed on CPU: 256 images, EIGHT ranks over gloo,
+    file sizes spread over a factor of 300 (five large files among many small ones).  The gathered CSV equals the one-rank run's, the ranks' byte
+    loads are within 10 %, the shards differ in length and the gather buffer is sized by the longest one.
+    (The encode is the scripted, GPU-free one of tests/_dist_worker.py: the search through the C ABI on a
+    score table derived from the file name -- sharding, record packing and the one all_gather are the
+    batch driver's own.)  No scaling figure follows from this: nothing multi-GPU has run on hardware."""
+    d = tmp_path / "imgs256"
+    d.mkdir()
+    rng = np.random.default_rng(42)
+    for k in range(256):
+        n = 600_000 if k % 51 == 7 else int(2_000 * 20.0 ** rng.random())   # five large files among many small ones
+        (d / f"img_{k:03d}.png").write_bytes(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    single, _ = _run(1, d, tmp_path / "s1.json")
+    eight, summary = _run(8, d, tmp_path / "s8.json")
+    assert single == eight and len(single) == 256 and all(r[2] == "ok" for r in single)
+
+    def rows(path):   # every column but the wall-clock one
+        return [r[:5] + r[6:] for r in csv.reader(open(path))]
+    assert rows(str(tmp_path / "s1.json") + ".csv") == rows(str(tmp_path / "s8.json") + ".csv")
+    r = [json.load(open(f"{tmp_path / 's8.json'}.rank{k}")) for k in range(8)]
+    assert sorted(sum((x["indices"] for x in r), [])) == list(range(256))
+    loads = [x["bytes"] for x in r]
+    assert max(loads) <= 1.10 * min(loads), loads
+    counts = [len(x["indices"]) for x in r]
+    assert len(set(counts)) > 1 and all(x["gather_rows_per_rank"] == max(counts) for x in r)   # uneven shards, one buffer size
+    assert "Ranks (GPUs): 8" in summary and "256 ok" in summary
+
+
 def test_world2_gloo_matches_single_process(image_dir, tmp_path):
     single, _ = _run(1, image_dir, tmp_path / "w1.json")
     double, summary = _run(2, image_dir, tmp_path / "w2.json")

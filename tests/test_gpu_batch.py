@@ -5,8 +5,10 @@ The pool gives one GPU per box, so the two ranks share device 0 through the batc
 `--procs-per-gpu 2` (rank r -> GPU r // 2; the one gather then runs over gloo, since RCCL does
 not place two ranks on one device).  What this covers of the 8-GPU path: the launcher, the
 largest-first dealing, host-core pinning, one scorer context per worker thread on the rank's
-device, the gather of result records, CSV and summary on rank 0.  What it does not: RCCL itself
-and 8 devices -- unmeasured until a SCALE record exists.  -m gpu only.
+device, the gather of result records, CSV and summary on rank 0.  What it does not: RCCL between
+devices and 8 devices -- unmeasured until a SCALE record exists.  RCCL itself is exercised as far as one GPU
+allows: a process group of ONE rank on backend "nccl" through which the batch driver sends its record gather
+(test_record_gather_runs_through_rccl_single_rank).  -m gpu only.
 """
 import csv
 import os
@@ -74,3 +76,51 @@ def test_batch_of_1080p_pngs_two_ranks_equals_one_rank(tmp_path):
     assert "[rank 0]" in p2.stderr and "[rank 1]" in p2.stderr
     # the "N passes" phrase measure.py parses (measure.py:27) is on every per-image line
     assert p2.stderr.count(" passes)") >= 16
+
+
+def test_record_gather_runs_through_rccl_single_rank(tmp_path):
+    """`gather_records`' device-tensor all_gather has to have executed on RCCL at least
+    once.  A one-GPU box cannot hold two RCCL ranks, so: backend "nccl", world size 1, the early return of a
+    one-rank group lifted (OAVIF_GATHER_ALWAYS=1) -- first the function alone on a hand-made record table with
+    a buffer larger than the shard, then the whole batch driver, whose CSV must equal the plain run's.
+    Subprocesses: a process group is process-wide state that must not leak into the other tests."""
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+from oavif_amd import batch
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(0)
+local = np.zeros((37, batch.RECORD_FIELDS), np.float64)
+local[:, 0] = rng.permutation(37)
+local[:, 1:] = rng.uniform(-1, 100, (37, batch.RECORD_FIELDS - 1))
+assert dist.get_backend() == "nccl"
+got = batch.gather_records(local, 37, device=torch.device("cuda", 0), per_rank=64, always=True)
+assert got.shape == (37, batch.RECORD_FIELDS) and np.array_equal(got, local[np.argsort(local[:, 0])])
+plain = batch.gather_records(local, 37, device=torch.device("cuda", 0), per_rank=64)     # early return of a one-rank group
+assert np.array_equal(plain, got)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl gather ok")
+""" % (ROOT, _free_port())
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0 and "rccl gather ok" in p.stdout, p.stderr[-2000:]
+    if not synth.have_avif():
+        return
+    from PIL import Image
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    for k in range(4):
+        Image.fromarray(synth.make_ref(320 + 16 * k, 200, 880 + k)).save(img_dir / f"g{k}.png")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = []
+    for tag, extra in (("plain", {}), ("rccl", {"OAVIF_GATHER_ALWAYS": "1", "MASTER_PORT": str(_free_port())})):
+        csv_path = tmp_path / f"{tag}.csv"
+        q = subprocess.run([sys.executable, "-m", "oavif_amd.batch", str(img_dir), str(csv_path), "--workers", "2",
+                            "--out-dir", str(tmp_path / tag)], env=dict(env, **extra), cwd=ROOT, capture_output=True,
+                           text=True, timeout=600)
+        assert q.returncode == 0, q.stderr[-2000:]
+        outs.append(_rows(csv_path))
+    assert outs[0] == outs[1] and len(outs[0][1]) == 4

@@ -196,8 +196,11 @@ def test_env_selects_the_mode_for_cli_and_batch(hip_lib, monkeypatch, rscorer):
     monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "recursive")
     with Ssimu2(0, blur=cli.blur_from_env()) as s:
         assert s.compute_ssimu2(ref, dist) == rscorer.compute_ssimu2(ref, dist)
-    with Ssimu2(0) as s:   # the library itself ignores the variable
+    with Ssimu2(0) as s:   # the library itself ignores the variable: a context starts in FIR mode
         fir = s.compute_ssimu2(ref, dist)
+    monkeypatch.delenv("OAVIF_SSIMU2_BLUR")
+    with Ssimu2(0, blur=cli.blur_from_env()) as s:   # unset: the search path's default is the recursion
+        assert s.compute_ssimu2(ref, dist) == rscorer.compute_ssimu2(ref, dist)
     monkeypatch.setenv("OAVIF_SSIMU2_BLUR", "fir")
     with Ssimu2(0, blur=cli.blur_from_env()) as s:
         assert s.compute_ssimu2(ref, dist) == fir

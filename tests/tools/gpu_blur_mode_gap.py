@@ -3,7 +3,9 @@ response vs the published recursion itself) as a function of frame size, on real
 the recursion's rounding noise averages out over more pixels, so the modes agree better on large
 frames.  Prints per size the median / 95th percentile / max |score_FIR - score_recursive| and how
 often a target-quality search ends on the same quantizer in both modes.
-Usage: gpu_blur_mode_gap.py [IMAGES_PER_SIZE]"""
+Usage: gpu_blur_mode_gap.py [IMAGES_PER_SIZE] [--only WxH] [--json PATH]
+--json writes one record per search (seed, target, the quantizer and score each mode ends on, passes) -- the
+4K record of round 4 is profiles/r04_4k_search_both_modes.json (24 searches: 6 images x 4 targets)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,11 +13,24 @@ import numpy as np
 import oavif_amd
 from oavif_amd import synth, tq
 
-n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+import json
+argv = sys.argv[1:]
+json_path = only = None
+if "--json" in argv:
+    json_path = argv[argv.index("--json") + 1]
+    del argv[argv.index("--json"):argv.index("--json") + 2]
+if "--only" in argv:
+    only = tuple(int(v) for v in argv[argv.index("--only") + 1].split("x"))
+    del argv[argv.index("--only"):argv.index("--only") + 2]
+n_img = int(argv[0]) if argv else 6
 sizes = [(384, 256), (640, 360), (1280, 720), (1920, 1080), (3840, 2160)]
+if only:
+    sizes = [only]
+records = []
 targets = [60.0, 70.0, 80.0, 88.0]
 fir = oavif_amd.Ssimu2(0)
 rec = oavif_amd.Ssimu2(0, blur=oavif_amd._lib.BLUR_RECURSIVE)
+fma = oavif_amd.Ssimu2(0, blur=oavif_amd._lib.BLUR_RECURSIVE_FMA)
 rng = np.random.default_rng(7)
 for (w, h) in sizes:
     gaps, same, n, dq, t0 = [], 0, 0, [], time.time()
@@ -35,11 +50,29 @@ for (w, h) in sizes:
             n += 1
             same += a.q == b.q
             dq.append(abs(a.q - b.q))
+            if json_path:
+                c = tq.search_hip(fma, ref, codec, score_tgt=tgt)
+                records.append({"width": w, "height": h, "image": i, "seed": 9100 + 17 * i + w, "extra_noise": i % 3 == 1,
+                                "target": tgt, "q_fir": a.q, "q_recursive": b.q, "q_recursive_fma": c.q,
+                                "score_fir": round(a.score, 4), "score_recursive": round(b.score, 4),
+                                "score_recursive_fma": round(c.score, 4), "passes_fir": a.num_pass,
+                                "passes_recursive": b.num_pass, "passes_recursive_fma": c.num_pass,
+                                "probes_fir": [[q, round(sc_, 4)] for q, sc_ in a.history],
+                                "probes_recursive": [[q, round(sc_, 4)] for q, sc_ in b.history]})
         for q in sorted(cache):
             gaps.append(abs(fir.compute_ssimu2(ref, cache[q][0]) - rec.compute_ssimu2(ref, cache[q][0])))
     g = np.array(gaps)
     print(f"{w}x{h}: {len(g)} probes, |score_fir - score_recursive| median {np.median(g):.4f}  95th pct "
           f"{np.percentile(g, 95):.4f}  max {g.max():.4f};  same final quantizer in {same} of {n} searches "
           f"(largest |dq| {max(dq)})  [{time.time() - t0:.0f}s]", flush=True)
+if json_path:
+    nsame = sum(r["q_fir"] == r["q_recursive"] for r in records)
+    json.dump({"what": "target-quality searches (tq.zig:124-210 restated, real AVIF probes through Pillow's libavif/aom speed 9) "
+                       "driven by the HIP scorer in each blur mode; which mode fssimu2 0.1.1 follows is unknown (parity unpinned)",
+               "searches": len(records), "same_quantizer_fir_vs_recursive": nsame,
+               "same_quantizer_recursive_vs_recursive_fma": sum(r["q_recursive"] == r["q_recursive_fma"] for r in records),
+               "largest_abs_dq_fir_vs_recursive": max(abs(r["q_fir"] - r["q_recursive"]) for r in records),
+               "records": records}, open(json_path, "w"), indent=1)
 fir.close()
 rec.close()
+fma.close()
