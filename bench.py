@@ -495,6 +495,15 @@ def main() -> int:
             "achieved": round(ALGO_BYTES_PER_PX_SCORE * w * h / (score_ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ALGO_BYTES_PER_PX_SCORE * w * h / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # what a second context buys (stream placement, DESIGN section 4 "Two scores in flight"): the timed
+        # two-context step against one context scoring the same rotation.  A reported number, not a test
+        # criterion (tests/test_gpu_streams.py asserts collision detection only): 0.84-0.89 across boxes;
+        # 1.0 would mean the two contexts' streams share a hardware queue.
+        if nctx >= 2:
+            out["two_context_ratio"] = {"value": round(out["ms_per_step"] / score_ms, 3),
+                                        "ms_per_score_two_contexts": out["ms_per_step"],
+                                        "ms_per_score_one_context": round(score_ms, 5),
+                                        "placed_streams": iscorer.placed_streams()}
         iscorer.close()
 
         # ---- the search's per-pass score: reference cached on the device (tq.zig:37 passes the

@@ -115,6 +115,11 @@ int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uin
 typedef int (*oavif_tq_batch_probe_fn)(void* user, const uint32_t* qs, uint32_t n, double* out_scores);
 
 typedef struct {
+    /* sizeof(oavif_tq_spec_options) as the CALLER compiled it (ABI guard, since library version v7: the struct
+       grew once already, and a caller built against a shorter layout would have the library read whatever
+       follows its struct).  The library refuses a size it does not know with SSIMU2_ERR_INVALID_ARG; members
+       beyond a known shorter size take their defaults.  OAVIF_TQ_SPEC_OPTIONS_INIT fills it in. */
+    uint32_t struct_size;
     uint32_t max_fanout; /* probes per wave, 1..OAVIF_TQ_MAX_FANOUT; 1 = the sequential search */
     /* Probes of the FIRST wave, 1..max_fanout; 0 = max_fanout.  The first probe of a search is the
        model's guess (tq.zig:40-43), and many searches end on it: with 1 the first wave is that
@@ -123,6 +128,8 @@ typedef struct {
        there is a measured score to extrapolate from. */
     uint32_t first_wave_fanout;
 } oavif_tq_spec_options;
+#define OAVIF_TQ_SPEC_OPTIONS_INIT(max_fanout_, first_wave_fanout_) \
+    { (uint32_t)sizeof(oavif_tq_spec_options), (max_fanout_), (first_wave_fanout_) }
 
 typedef struct {
     uint32_t waves;         /* calls of `batch` (the latency of the search, in passes)          */

@@ -74,6 +74,10 @@ int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
    algorithmic bytes of one launch (every plane element read once, written once). */
 int ssimu2_time_blur_stage_rotating(ssimu2_ctx* ctx, const void* const* d_frames, int nframes, uint32_t w,
                                     uint32_t h, int iters, float* out_ms_avg, double* out_bytes_per_launch);
+/* Stream placement (ssimu2_hip.hip "stream placement"): how many streams on distinct hardware queues this
+   library instance holds for ctx's device -- contexts created without a caller stream borrow them in turn.
+   3 with HIP's default of four hardware queues; 1 would mean every probe misread (tests/test_gpu_streams.py). */
+int ssimu2_instr_placed_streams(ssimu2_ctx* ctx, int* out_n);
 /* recursive modes: keep the 15 raw planes of `scale` downloadable (SSIMU2_DEBUG_RG_H / _RG_V) --
    the horizontal-pass planes are copied out of the pass buffer, the vertical-pass planes of the
    distorted frame, which otherwise exist only in LDS, are recomputed into a debug buffer; the score

@@ -68,7 +68,11 @@ class PngInfo(ctypes.Structure):   # oavif_png_info (include/oavif_tq.h)
 
 
 class TQSpecOptions(ctypes.Structure):
-    _fields_ = [("max_fanout", ctypes.c_uint32), ("first_wave_fanout", ctypes.c_uint32)]
+    """oavif_tq_spec_options; struct_size is the ABI guard (include/oavif_tq.h), filled in here."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("max_fanout", ctypes.c_uint32), ("first_wave_fanout", ctypes.c_uint32)]
+
+    def __init__(self, max_fanout: int = 1, first_wave_fanout: int = 0):
+        super().__init__(ctypes.sizeof(TQSpecOptions), int(max_fanout), int(first_wave_fanout))
 
 
 class TQSpecStats(ctypes.Structure):
@@ -80,7 +84,8 @@ class TQSpecStats(ctypes.Structure):
 INSTR_SYMBOLS = ("ssimu2_debug_download", "ssimu2_time_device", "ssimu2_time_stage",
                  "ssimu2_time_march_rotating", "ssimu2_measure_read_stream",
                  "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur",
-                 "ssimu2_instr_rg_stop_after_scale", "ssimu2_time_blur_stage_rotating")
+                 "ssimu2_instr_rg_stop_after_scale", "ssimu2_time_blur_stage_rotating",
+                 "ssimu2_instr_placed_streams")
 
 TQ_MAX_FANOUT = 16
 BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
@@ -173,6 +178,7 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
             "ssimu2_instr_set_segment_rows": [vp, ci, ci],
             "ssimu2_instr_cache_reference_blur": [vp, ci],
             "ssimu2_instr_rg_stop_after_scale": [vp, ci],
+            "ssimu2_instr_placed_streams": [vp, ctypes.POINTER(ci)],
             "ssimu2_time_blur_stage_rotating": [vp, ctypes.POINTER(vp), ci, u32, u32, ci,
                                                 ctypes.POINTER(ctypes.c_float), f64p],
         }

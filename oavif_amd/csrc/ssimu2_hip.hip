@@ -656,7 +656,7 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v6 (pair ring, b64 taps, dword pixel loads; recursive blur: cached reference, 3 lanes per line; placed streams)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v7 (pair ring, b64 taps, dword pixel loads; recursive blur: cached reference, 3 lanes per line, persistent vertical pass; placed streams; sized option structs)"; }
 
 int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
@@ -714,23 +714,39 @@ StreamPool g_pool[64];
 // the two streams share the queue: >= 300 us then, 200 us on distinct queues.  (One kernel per
 // stream proves nothing: without a barrier between them two packets of one queue run side by side.)
 bool streams_overlap(hipStream_t a, hipStream_t b) {
+    // Timed on the DEVICE (events on the two streams), best of four: a host clock around launch and
+    // synchronize adds the launch path and the wake-up of the waiting thread to a 200-vs-300 us
+    // decision, and one misread on a loaded host shrank the set to a single stream.
     const long long ticks = 10000;  // 100 us
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (ea) (void)hipEventDestroy(ea);
+        (void)hipGetLastError();
+        return false;
+    }
     double best = 1e9;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 4; ++rep) {
         (void)hipStreamSynchronize(a);
         (void)hipStreamSynchronize(b);
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
+        (void)hipEventRecord(e0, a);
         for (int k = 0; k < 2; ++k) {
             hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
             hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
         }
+        (void)hipEventRecord(ea, a);
+        (void)hipEventRecord(eb, b);
         (void)hipStreamSynchronize(a);
         (void)hipStreamSynchronize(b);
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        float ma = 0.f, mb = 0.f;
+        if (hipEventElapsedTime(&ma, e0, ea) != hipSuccess || hipEventElapsedTime(&mb, e0, eb) != hipSuccess) continue;
+        const double us = 1e3 * (ma > mb ? ma : mb);
         if (us < best) best = us;
     }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
     return best < 260.0;
 }
 
@@ -770,6 +786,13 @@ hipStream_t pool_acquire(int device) {
             return pool.stream[i];
         }
     return nullptr;
+}
+
+// streams of the placed set of `device` (0 before the first context without a caller stream exists)
+int pool_size(int device) {
+    if (device < 0 || device >= 64) return 0;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    return g_pool[device].n;
 }
 
 void pool_release(int device, hipStream_t s) {

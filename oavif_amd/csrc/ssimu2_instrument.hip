@@ -57,6 +57,12 @@ int ssimu2_instr_set_segment_rows(ssimu2_ctx* c, int rows_scale0, int rows_other
     return SSIMU2_OK;
 }
 
+int ssimu2_instr_placed_streams(ssimu2_ctx* c, int* out_n) {
+    if (!c || !out_n) return SSIMU2_ERR_INVALID_ARG;
+    *out_n = pool_size(c->device);
+    return SSIMU2_OK;
+}
+
 int ssimu2_instr_rg_stop_after_scale(ssimu2_ctx* c, int scale) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
     c->rg_dbg_scale = scale < 0 || scale >= kNumScales ? -1 : scale;

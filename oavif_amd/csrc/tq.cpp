@@ -317,12 +317,17 @@ int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
                                              oavif_tq_batch_probe_fn batch, void* user,
                                              oavif_tq_result* out, oavif_tq_spec_stats* stats) {
     if (!o || !so || !batch || !out) return SSIMU2_ERR_INVALID_ARG;
+    // ABI guard: the layouts this library knows are {struct_size, max_fanout} (12 bytes would be today's;
+    // 8 = a caller that stops before first_wave_fanout, which then takes its default 0 = max_fanout)
+    if (so->struct_size != sizeof(oavif_tq_spec_options) && so->struct_size != 2 * sizeof(uint32_t))
+        return SSIMU2_ERR_INVALID_ARG;
+    const uint32_t first_wave = so->struct_size >= sizeof(oavif_tq_spec_options) ? so->first_wave_fanout : 0u;
     if (so->max_fanout < 1 || so->max_fanout > OAVIF_TQ_MAX_FANOUT) return SSIMU2_ERR_INVALID_ARG;
-    if (so->first_wave_fanout > so->max_fanout) return SSIMU2_ERR_INVALID_ARG;
+    if (first_wave > so->max_fanout) return SSIMU2_ERR_INVALID_ARG;
     Spec s{};
     s.o = o;
     s.fanout = so->max_fanout;
-    s.first_fanout = so->first_wave_fanout ? so->first_wave_fanout : so->max_fanout;
+    s.first_fanout = first_wave ? first_wave : so->max_fanout;
     s.batch = batch;
     s.user = user;
     const int rc = oavif_tq_find_target_quality(o, replay_probe, &s, out);

@@ -209,6 +209,16 @@ class Ssimu2:
         if rc != 0:
             self._raise(rc)
 
+    def placed_streams(self) -> int:
+        """Instrumented build: streams on distinct hardware queues its library instance holds for this
+        context's device (ssimu2_instr_placed_streams)."""
+        self._need_instr()
+        n = ctypes.c_int(0)
+        rc = self._L.ssimu2_instr_placed_streams(self._ctx, ctypes.byref(n))
+        if rc != 0:
+            self._raise(rc)
+        return int(n.value)
+
     def rg_stop_after_scale(self, scale: int) -> None:
         """Instrumented build: the recursive mode keeps the 15 raw planes of `scale` (after the
         horizontal pass and after both passes) downloadable (debug_download what = 4 / 5);

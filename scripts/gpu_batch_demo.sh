@@ -12,10 +12,10 @@ for i in range($N):
 PY
 for w in 1 16; do
   echo "== workers=$w"
-  python -m oavif_amd.batch $D/imgs $D/out_$w.csv --workers $w --out-dir $D/o$w 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average encoding|Average passes"
+  python -m oavif_amd.batch $D/imgs $D/out_$w.csv --workers $w --out-dir $D/o$w 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average encoding|Average passes|Host cores"
 done
-echo "== workers=default, published-recursion blur mode (OAVIF_SSIMU2_BLUR=recursive)"
-OAVIF_SSIMU2_BLUR=recursive python -m oavif_amd.batch $D/imgs $D/out_r.csv --out-dir $D/or 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average passes|Worker threads"
+echo "== workers=default, FIR blur mode (OAVIF_SSIMU2_BLUR=fir; the runs above and below use the search path's default, the published recursion)"
+OAVIF_SSIMU2_BLUR=fir python -m oavif_amd.batch $D/imgs $D/out_r.csv --out-dir $D/or 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average passes|Worker threads|Host cores"
 for k in 2 4; do
 echo "== --procs-per-gpu $k: $k ranks on GPU 0 (the gather over gloo), pinned to disjoint host cores, largest file first"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node $k --master-addr 127.0.0.1 --master-port 2953$k \

@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
         for (uint32_t fan : {1u, 2u, 5u, (uint32_t)OAVIF_TQ_MAX_FANOUT}) {
             Table t2 = t;
             t2.calls = 0;
-            oavif_tq_spec_options so = {fan, (uint32_t)(iter % 2 ? 1 : 0)};  // every other search: the first wave alone
+            oavif_tq_spec_options so = OAVIF_TQ_SPEC_OPTIONS_INIT(fan, (uint32_t)(iter % 2 ? 1 : 0));  // every other search: the first wave alone
             oavif_tq_result r2;
             oavif_tq_spec_stats st;
             std::memset(&r2, 0xCD, sizeof r2);
@@ -177,11 +177,21 @@ int main(int argc, char** argv) {
         CHECK(oavif_tq_find_target_quality(nullptr, table_probe, &t, &r) != 0);
         CHECK(oavif_tq_find_target_quality(&o, nullptr, &t, &r) != 0);
         CHECK(oavif_tq_find_target_quality(&o, table_probe, &t, nullptr) != 0);
-        oavif_tq_spec_options so = {0, 0};
+        oavif_tq_spec_options so = OAVIF_TQ_SPEC_OPTIONS_INIT(0, 0);
         oavif_tq_spec_stats st;
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
         so.max_fanout = OAVIF_TQ_MAX_FANOUT + 1;
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
+        // the ABI guard: a struct_size the library does not know is refused; the round-2 layout (no
+        // first_wave_fanout behind max_fanout) is accepted and means first_wave_fanout = 0
+        so.max_fanout = 4;
+        so.struct_size = 4;
+        CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
+        so.struct_size = 64;
+        CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
+        so.struct_size = 8;
+        so.first_wave_fanout = 0xFFFFFFFFu;  // not read at this size
+        CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) == 0);
         o.max_pass = 0;
         CHECK(oavif_tq_find_target_quality(&o, table_probe, &t, &r) != 0);
         o.max_pass = OAVIF_TQ_MAX_PASS + 1;
