@@ -325,6 +325,7 @@ PyrBandArgs pyramid_args(const Pyramid& p, int nframes, const uint8_t* const* fr
     for (int l = 0; l < p.nscales; ++l) {
         a.w[l] = p.w[l];
         a.h[l] = p.h[l];
+        a.opitch[l] = p.w[l];  // tight rows (the linear-light pyramid); rg_launch_convert pads them
     }
     a.nframes = nframes;
     a.bands_x = (p.w[0] + PYR_BAND_W - 1) / PYR_BAND_W;
@@ -387,7 +388,7 @@ void build_plans(const ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref, co
 // plane offset (floats per plane) of scale s in the packed recursive-mode buffers
 size_t rg_plane_off(const Pyramid& p, int s) {
     size_t off = 0;
-    for (int k = 0; k < s; ++k) off += (size_t)p.w[k] * p.h[k];
+    for (int k = 0; k < s; ++k) off += (size_t)rg_pitch(p.w[k]) * p.h[k];  // rows padded to 128 floats ("Row pitch")
     return off;
 }
 
@@ -403,7 +404,7 @@ int rg_check_size(ssimu2_ctx* c, uint32_t w, uint32_t h) {
 // (its planes live here).
 int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
     const size_t ntot = rg_plane_off(p, p.nscales);
-    const size_t need = 21 * ntot + (size_t)p.w[0] + 16;  // + the dump row of k_rg_v_emit
+    const size_t need = 21 * ntot + (size_t)rg_pitch(p.w[0]) + 16;  // + the dump row of k_rg_v_emit
     size_t need_part = 8;
     for (int s = 0; s < p.nscales; ++s) need_part += (size_t)kStats * ((p.w[s] + RG_VW - 1) / RG_VW);
     if (need > c->cap_rg || need_part > c->cap_rg_part) {
@@ -432,7 +433,7 @@ int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
         c->num_cus = cus;
     }
     if (c->rg_dbg_scale >= 0 && c->rg_dbg_scale < p.nscales) {
-        const size_t nd = (size_t)24 * p.w[c->rg_dbg_scale] * p.h[c->rg_dbg_scale] + 16;  // 15 h planes + 9 v planes
+        const size_t nd = (size_t)24 * rg_pitch(p.w[c->rg_dbg_scale]) * p.h[c->rg_dbg_scale] + 16;  // 15 h planes + 9 v planes
         if (nd > c->cap_rg_dbg) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             (void)hipFree(c->d_rg_dbg);
@@ -465,6 +466,7 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, bool ref_frame, RgPlan
         const size_t off = rg_plane_off(p, s);
         rp->w[s] = p.w[s];
         rp->h[s] = p.h[s];
+        rp->pitch[s] = rg_pitch(p.w[s]);
         hb_ += 3 * ((p.h[s] + RG_HL - 1) / RG_HL);
         rp->vgroups[s] = (p.w[s] + RG_VW - 1) / RG_VW;
         vb_ += 3 * rp->vgroups[s];
@@ -511,7 +513,7 @@ bool rg_debugging(const ssimu2_ctx* c, const Pyramid& p) {
 
 void rg_debug_keep_h(ssimu2_ctx* c, const Pyramid& p, const RgPlan& rp, bool ref) {
     const int s = c->rg_dbg_scale, nk = ref ? 2 : 3;
-    const size_t n = (size_t)p.w[s] * p.h[s];
+    const size_t n = (size_t)rg_pitch(p.w[s]) * p.h[s];
     for (int ch = 0; ch < 3; ++ch)
         for (int k = 0; k < nk; ++k)
             (void)hipMemcpyAsync(c->d_rg_dbg + (size_t)rg_plane15(ref, ch, k) * n, rp.hbuf[s] + (size_t)(ch * nk + k) * n,
@@ -527,6 +529,7 @@ void rg_launch_convert(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, 
     a.xyb0[0] = rp.xout[0];
     a.zero4 = rp.q;
     for (int l = 0; l < a.nlevels; ++l) a.out[0][l] = rp.xout[l + 1];
+    for (int l = 0; l < p.nscales && l < 6; ++l) a.opitch[l] = rp.pitch[l];
     hipLaunchKernelGGL(k_pyramid_bands_xyb, dim3(a.bands_x * a.bands_y), dim3(PYR_THREADS), 0, c->stream, a);
 }
 
@@ -576,7 +579,7 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
         if (dbg) {
             rg_debug_keep_h(c, p, rp, false);
             const int s = c->rg_dbg_scale;
-            rp.emit[s] = c->d_rg_dbg + (size_t)15 * p.w[s] * p.h[s];  // [channel][{y, yy, xy}][n]
+            rp.emit[s] = c->d_rg_dbg + (size_t)15 * rg_pitch(p.w[s]) * p.h[s];  // [channel][{y, yy, xy}][n]
             if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
             else hipLaunchKernelGGL((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
         }

@@ -93,23 +93,26 @@ int ssimu2_debug_download(ssimu2_ctx* c, int what, int scale, uint32_t w, uint32
         // 15 raw planes of the scale selected with ssimu2_instr_rg_stop_after_scale before the score
         if (scale < 0 || scale >= p.nscales || scale != c->rg_dbg_scale || !c->d_rg_dbg || !c->d_rg)
             return c->fail(SSIMU2_ERR_INVALID_ARG, "no recursive-blur planes kept for that scale");
-        const size_t n1 = (size_t)p.w[scale] * p.h[scale];
-        if (24 * n1 > c->cap_rg_dbg) return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive-blur planes are of another frame size");
+        // device planes keep their rows rg_pitch(w) floats apart (ssimu2_recursive.h "Row pitch"); `out` is tight
+        const size_t pitch = (size_t)rg_pitch(p.w[scale]), wd = (size_t)p.w[scale], ht = (size_t)p.h[scale];
+        const size_t nd = pitch * ht, n1 = wd * ht;
+        if (24 * nd > c->cap_rg_dbg) return c->fail(SSIMU2_ERR_INVALID_ARG, "recursive-blur planes are of another frame size");
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        auto plane = [&](float* dst, const float* src) {
+            return hipMemcpy2D(dst, wd * sizeof(float), src, pitch * sizeof(float), wd * sizeof(float), ht, hipMemcpyDeviceToHost);
+        };
         if (what == SSIMU2_DEBUG_RG_H) {
-            HIP_TRY(c, hipMemcpy(out, c->d_rg_dbg, 15 * n1 * sizeof(float), hipMemcpyDeviceToHost));
+            for (int k = 0; k < 15; ++k) HIP_TRY(c, plane(out + (size_t)k * n1, c->d_rg_dbg + (size_t)k * nd));
         } else {
             // x, xx: the reference cache [channel][{mu1, s11}]; y, yy, xy: k_rg_v_emit's planes
             const float* cache = c->d_rg + 6 * rg_plane_off(p, p.nscales) + 6 * rg_plane_off(p, scale);
-            const float* pass = c->d_rg_dbg + 15 * n1;
+            const float* pass = c->d_rg_dbg + 15 * nd;
             for (int ch = 0; ch < 3; ++ch) {
                 for (int k = 0; k < 2; ++k)
-                    HIP_TRY(c, hipMemcpy(out + (size_t)rg_plane15(true, ch, k) * n1, cache + (size_t)(ch * 2 + k) * n1,
-                                         n1 * sizeof(float), hipMemcpyDeviceToHost));
+                    HIP_TRY(c, plane(out + (size_t)rg_plane15(true, ch, k) * n1, cache + (size_t)(ch * 2 + k) * nd));
                 for (int k = 0; k < 3; ++k)
-                    HIP_TRY(c, hipMemcpy(out + (size_t)rg_plane15(false, ch, k) * n1, pass + (size_t)(ch * 3 + k) * n1,
-                                         n1 * sizeof(float), hipMemcpyDeviceToHost));
+                    HIP_TRY(c, plane(out + (size_t)rg_plane15(false, ch, k) * n1, pass + (size_t)(ch * 3 + k) * nd));
             }
         }
         if (out_w) *out_w = (uint32_t)p.w[scale];

@@ -174,6 +174,8 @@ struct PyrBandArgs {
     float* out[2][5];      // per frame: planes [3][h_l][w_l] of levels 1..5 (entries >= nlevels unused)
     float* xyb0[2];        // XYB variant only: positive-XYB planes [3][h_0][w_0] of the frame itself
     int w[6], h[6];        // level dimensions, [0] = the 8-bit frame
+    int opitch[6];         // floats per row of the OUTPUT planes of each level (= w[] for the linear pyramid; the
+                           // recursive modes pad their rows to 128 floats, ssimu2_recursive.h "Row pitch")
     int nlevels;           // levels to produce: 1..5; 0 = nothing to do
     int bands_x, bands_y, nframes;
     unsigned* zero4;       // XYB variant: four job cursors of the recursive passes that follow in the stream, zeroed here
@@ -207,21 +209,21 @@ __device__ __forceinline__ void pyr_store_xyb(float* out, size_t n, size_t at, c
 // (2*ox0, 2*oy0) of the level above, whose size is wa x ha), outputs ox0+lx, oy0+ly.
 template <bool XYB>
 __device__ __forceinline__ void pyr_lds_level(const float* src, int sw, int sh, int wa, int ha, float* dst_tile,
-                                              int dw_tile, int dh_tile, float* out, int wo, int ho, int ox0,
+                                              int dw_tile, int dh_tile, float* out, int wo, int ho, int po, int ox0,
                                               int oy0, int lx, int ly) {
     const int ox = ox0 + lx, oy = oy0 + ly;
     float v[3] = {0.f, 0.f, 0.f};
     if (ox < wo && oy < ho) {
         const int xa = 2 * lx, xb = min(2 * ox + 1, wa - 1) - 2 * ox0;
         const int ya = 2 * ly, yb = min(2 * oy + 1, ha - 1) - 2 * oy0;
-        const size_t n = (size_t)wo * ho;
+        const size_t n = (size_t)po * ho;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* p = src + c * sw * sh;
             v[c] = box4(p[ya * sw + xa], p[ya * sw + xb], p[yb * sw + xa], p[yb * sw + xb]);
-            if (!XYB) out[c * n + (size_t)oy * wo + ox] = v[c];
+            if (!XYB) out[c * n + (size_t)oy * po + ox] = v[c];
         }
-        if (XYB) pyr_store_xyb(out, n, (size_t)oy * wo + ox, v);
+        if (XYB) pyr_store_xyb(out, n, (size_t)oy * po + ox, v);
     }
     if (dst_tile) {
 #pragma unroll
@@ -284,7 +286,8 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
         }
         // byte 3*i + c of a row = channel c of pixel i
 #define PYR_LIN(j, i, c) lut[(raw[j][(3 * (i) + (c)) >> 2] >> (8 * ((3 * (i) + (c)) & 3))) & 255u]
-        const size_t n1 = (size_t)w1 * h1;
+        const int p1 = a.opitch[1];
+        const size_t n1 = (size_t)p1 * h1;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -297,16 +300,17 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                 if (ox < w1 && oy < h1 && (!XYB || a.nlevels >= 1)) {
                     float* o = a.out[f][0];
                     if (XYB) {
-                        pyr_store_xyb(o, n1, (size_t)oy * w1 + ox, l1[j][i]);
+                        pyr_store_xyb(o, n1, (size_t)oy * p1 + ox, l1[j][i]);
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * w1 + ox] = l1[j][i][c];
+                        for (int c = 0; c < 3; ++c) o[c * n1 + (size_t)oy * p1 + ox] = l1[j][i][c];
                     }
                 }
             }
         }
         if (XYB) {  // the frame's own XYB planes: this thread's 4 x 4 pixels, a row of four at a time
-            const size_t n0 = (size_t)w0 * h0;
+            const int p0 = a.opitch[0];
+            const size_t n0 = (size_t)p0 * h0;
             float* o = a.xyb0[f];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -316,7 +320,7 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                     linear_to_xyb(PYR_LIN(j, i, 0), PYR_LIN(j, i, 1), PYR_LIN(j, i, 2), px[0][i], px[1][i], px[2][i]);
                 }
                 if (inside) {
-                    const size_t at = (size_t)(Y0 + j) * w0 + X0;
+                    const size_t at = (size_t)(Y0 + j) * p0 + X0;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) __builtin_memcpy(o + c * n0 + at, px[c], 16);
                 } else if (Y0 + j < h0) {
@@ -324,7 +328,7 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                     for (int i = 0; i < 4; ++i)
                         if (X0 + i < w0) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) o[c * n0 + (size_t)(Y0 + j) * w0 + X0 + i] = px[c][i];
+                            for (int c = 0; c < 3; ++c) o[c * n0 + (size_t)(Y0 + j) * p0 + X0 + i] = px[c][i];
                         }
                 }
             }
@@ -339,7 +343,8 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
         if (ox < w2 && oy < h2) {
             // the level-1 column / row 2*ox+1, 2*oy+1 may not exist: the published clamp repeats the last one
             const int ib = min(2 * ox + 1, w1 - 1) - 2 * ox, jb = min(2 * oy + 1, h1 - 1) - 2 * oy;
-            const size_t n2 = (size_t)w2 * h2;
+            const int p2 = a.opitch[2];
+            const size_t n2 = (size_t)p2 * h2;
             float* o = a.out[f][1];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -347,9 +352,9 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
                 const float p10 = jb ? l1[1][0][c] : l1[0][0][c];
                 const float p11 = jb ? (ib ? l1[1][1][c] : l1[1][0][c]) : (ib ? l1[0][1][c] : l1[0][0][c]);
                 v[c] = box4(l1[0][0][c], p01, p10, p11);
-                if (!XYB) o[c * n2 + (size_t)oy * w2 + ox] = v[c];
+                if (!XYB) o[c * n2 + (size_t)oy * p2 + ox] = v[c];
             }
-            if (XYB) pyr_store_xyb(o, n2, (size_t)oy * w2 + ox, v);
+            if (XYB) pyr_store_xyb(o, n2, (size_t)oy * p2 + ox, v);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) s2[(c * 8 + ty) * TX + tx] = v[c];
@@ -357,17 +362,17 @@ __device__ __forceinline__ void pyramid_band(const PyrBandArgs& a, int band, con
     if (a.nlevels < 3) return;
     __syncthreads();
     if (t < 4 * (TX / 2))
-        pyr_lds_level<XYB>(s2, TX, 8, a.w[2], a.h[2], s3, TX / 2, 4, a.out[f][2], a.w[3], a.h[3], bx * (TX / 2), by * 4,
+        pyr_lds_level<XYB>(s2, TX, 8, a.w[2], a.h[2], s3, TX / 2, 4, a.out[f][2], a.w[3], a.h[3], a.opitch[3], bx * (TX / 2), by * 4,
                       t % (TX / 2), t / (TX / 2));
     if (a.nlevels < 4) return;
     __syncthreads();
     if (t < 2 * (TX / 4))
-        pyr_lds_level<XYB>(s3, TX / 2, 4, a.w[3], a.h[3], s4, TX / 4, 2, a.out[f][3], a.w[4], a.h[4], bx * (TX / 4), by * 2,
+        pyr_lds_level<XYB>(s3, TX / 2, 4, a.w[3], a.h[3], s4, TX / 4, 2, a.out[f][3], a.w[4], a.h[4], a.opitch[4], bx * (TX / 4), by * 2,
                       t % (TX / 4), t / (TX / 4));
     if (a.nlevels < 5) return;
     __syncthreads();
     if (t < TX / 8)
-        pyr_lds_level<XYB>(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], bx * (TX / 8), by, t, 0);
+        pyr_lds_level<XYB>(s4, TX / 4, 2, a.w[4], a.h[4], nullptr, 0, 0, a.out[f][4], a.w[5], a.h[5], a.opitch[5], bx * (TX / 8), by, t, 0);
 }
 
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_bands(PyrBandArgs a) {

@@ -46,9 +46,19 @@ constexpr int RG_VB = 2 * RG_N; // rows per batch of the vertical pass
 constexpr int RG_VW = 64;       // columns per workgroup of the vertical pass
 constexpr int RG_MAPS_WAVES = RG_VB / 2;  // each maps wave owns two rows of every batch
 
+// Row pitch.  Every plane of the recursive modes -- XYB, cached reference, horizontal pass -- keeps its
+// rows RG_PITCH_ALIGN floats (512 bytes) apart-aligned: pitch = w rounded up.  Measured (round 4, same
+// pixels per frame): rows that do not start on 512 bytes cost k_rg_v 30-45 % and k_rg_h up to 35 %
+// (3856, 3904, 3776 wide against 3840 / 4096) -- each lane quad's 64-byte segment then straddles lines,
+// and the aligned 64-column stores of k_rg_h are aligned in no row but the first.  3 % more memory at
+// worst on a 4K-class frame; nothing changes for widths that are multiples of 128.
+constexpr int RG_PITCH_ALIGN = 128;
+__host__ __device__ __forceinline__ int rg_pitch(int w) { return (w + RG_PITCH_ALIGN - 1) / RG_PITCH_ALIGN * RG_PITCH_ALIGN; }
+
 struct RgPlan {
     int nscales;
     int w[kNumScales], h[kNumScales];
+    int pitch[kNumScales];        // floats per row of every plane of that scale (rg_pitch(w)); a plane is pitch * h floats
     int hblk_end[kNumScales];     // exclusive end of each scale's workgroups in the k_rg_h grid
     int vblk_end[kNumScales];     // ... in the k_rg_v grid
     int vgroups[kNumScales];      // column groups of a scale = partial sums per statistic
@@ -392,14 +402,14 @@ __global__ __launch_bounds__(64 * RG_HW) void k_rg_h_persistent(RgPlan p) {
         // jobs of a scale: row group, then channel, then plane -- neighbours share their inputs
         const int local = job - first;
         const int rgrp = local / (3 * NK), ch = local % (3 * NK) / NK, kind = local % NK;
-        const int w = p.w[sc], h = p.h[sc];
-        const size_t n = (size_t)w * h;
+        const int w = p.w[sc], h = p.h[sc], pitch = p.pitch[sc];
+        const size_t n = (size_t)pitch * h;
         L.w = w;
         // rows of the cooperative 16-byte accesses; rows behind the image shadow its last row (their
         // lines compute and store that row's values once more)
 #pragma unroll
         for (int i = 0; i < RG_TR; ++i)
-            L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)w + 4u * (uint32_t)(lane & 15);
+            L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)pitch + 4u * (uint32_t)(lane & 15);
         const float* xa = p.xa[sc] + ch * n;
         const float* xb = REF ? xa : p.xb[sc] + ch * n;
         L.gout = p.hbuf[sc] + (size_t)(ch * NK + kind) * n;
@@ -429,8 +439,8 @@ __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (cappe
     const int ch = blk % 3, rgrp = blk / 3;
     const int kind = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int w = p.w[sc], h = p.h[sc];
-    const size_t n = (size_t)w * h;
+    const int w = p.w[sc], h = p.h[sc], pitch = p.pitch[sc];
+    const size_t n = (size_t)pitch * h;
     RgLine L;
     // lane -> (DPP row, line, section); lane 15 of a row shadows line 4 / section 5 and holds nothing
     const int l16 = lane & 15;
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (cappe
     // lines compute and store that row's values once more)
 #pragma unroll
     for (int i = 0; i < RG_TR; ++i)
-        L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)w + 4u * (uint32_t)(lane & 15);
+        L.goff[i] = (uint32_t)min(rgrp * RG_HL + 4 * i + (lane >> 4), h - 1) * (uint32_t)pitch + 4u * (uint32_t)(lane & 15);
     const float* xa = p.xa[sc] + ch * n;
     const float* xb = REF ? xa : p.xb[sc] + ch * n;
     L.gout = p.hbuf[sc] + (size_t)(ch * NK + kind) * n;
@@ -495,7 +505,7 @@ __device__ __forceinline__ int rg_v_batches(int h) {
 }
 
 template <bool FMA, typename Emit>
-__device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w, int h, Emit emit) {
+__device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int pitch, int h, Emit emit) {
     const float n2[3] = {c_k.rg_n2[0], c_k.rg_n2[1], c_k.rg_n2[2]};
     const float d1[3] = {c_k.rg_d1[0], c_k.rg_d1[1], c_k.rg_d1[2]};
     const int nb = rg_v_batches(h);
@@ -505,8 +515,8 @@ __device__ __forceinline__ void rg_v_column(const float* __restrict__ in, int w,
     float q[RG_PF][RG_VB];  // queue slot b % PF holds rows 10 b .. 10 b + 9, as loaded
 #define RG_V_LOAD(B, SLOT)                                          \
     _Pragma("unroll") for (int j = 0; j < RG_VB; ++j)               \
-        q[SLOT][j] = RG_NT_LD ? __builtin_nontemporal_load(in + (size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * w) \
-                           : in[(size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * w];
+        q[SLOT][j] = RG_NT_LD ? __builtin_nontemporal_load(in + (size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * pitch) \
+                           : in[(size_t)min((RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j, h - 1) * pitch];
 #pragma unroll
     for (int j = 0; j < RG_VB; ++j) q[RG_PF - 1][j] = 0.f;  // batch -1: rows -10 .. -1
 #pragma unroll
@@ -551,17 +561,17 @@ __global__ __launch_bounds__(64 * NK) void k_rg_v_emit(RgPlan p) {
     const int blk = (int)blockIdx.x - first;
     const int ch = blk % 3, cg = blk / 3;
     const int kind = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int w = p.w[sc], h = p.h[sc];
-    const size_t n = (size_t)w * h;
+    const int w = p.w[sc], h = p.h[sc], pitch = p.pitch[sc];
+    const size_t n = (size_t)pitch * h;
     const int xc = min(cg * RG_VW + (int)(threadIdx.x & 63), w - 1);  // lanes right of the image shadow its last column
     const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
     float* out = p.emit[sc] + (size_t)(ch * NK + kind) * n;
     float* dump = p.dump;
-    rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
+    rg_v_column<FMA>(in, pitch, h, [&](int b, const float (&o)[RG_VB]) {
 #pragma unroll
         for (int j = 0; j < RG_VB; ++j) {
             const int r = b * RG_VB + j - (RG_N - 1);  // output row (uniform)
-            float* row = r >= 0 && r < h ? out + (size_t)r * w : dump;
+            float* row = r >= 0 && r < h ? out + (size_t)r * pitch : dump;
             row[xc] = o[j];
         }
     });
@@ -603,8 +613,8 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
             }
         const int blk = job - first;
         const int ch = blk % 3, cg = RG_EXP_V_REVERSE ? p.vgroups[sc] - 1 - blk / 3 : blk / 3;
-        const int w = p.w[sc], h = p.h[sc];
-        const size_t n = (size_t)w * h;
+        const int w = p.w[sc], h = p.h[sc], pitch = p.pitch[sc];
+        const size_t n = (size_t)pitch * h;
         const int x = cg * RG_VW + lane;
         const bool ok = x < w;
         const int xc = min(x, w - 1);
@@ -613,7 +623,7 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
         if (wave < NK) {
             const int kind = wave;
             const float* in = p.hbuf[sc] + (size_t)(ch * NK + kind) * n + xc;
-            rg_v_column<FMA>(in, w, h, [&](int b, const float (&o)[RG_VB]) {
+            rg_v_column<FMA>(in, pitch, h, [&](int b, const float (&o)[RG_VB]) {
 #pragma unroll
                 for (int j = 0; j < RG_VB; ++j) s_out[b & 1][kind][j][lane] = o[j];
                 __syncthreads();  // batch b is in the tile
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {
 #define RG_M_LOAD(B, SLOT)                                                     \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                         \
         const int r_ = (RG_EXP_V_SAMEROWS ? 0 : (B) * RG_VB) + j0 + jj - (RG_N - 1); \
-        const size_t o_ = (size_t)min(max(r_, 0), h - 1) * w;                  \
+        const size_t o_ = (size_t)min(max(r_, 0), h - 1) * pitch;              \
         g[SLOT][jj][0] = RG_NT_LD ? __builtin_nontemporal_load(g_mu1 + o_) : g_mu1[o_]; \
         g[SLOT][jj][1] = RG_NT_LD ? __builtin_nontemporal_load(g_s11 + o_) : g_s11[o_]; \
         g[SLOT][jj][2] = RG_NT_LD ? __builtin_nontemporal_load(g_r1 + o_) : g_r1[o_];   \
