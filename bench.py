@@ -579,7 +579,9 @@ def main() -> int:
                                  "per_pass_scratch": round(12 * n_tot * 4 / 1e6, 1)},
             "note": "SSIMU2_BLUR_RECURSIVE: the published recursive Gaussian operation for operation (planes "
                     "bit-identical to the oracle's OR_BLUR_IIR): one line = three lanes, all scales in one launch "
-                    "per stage, reference planes cached per search, v-pass fused with the maps"}
+                    "per stage, reference planes cached per search, v-pass fused with the maps and persistent "
+                    "(one workgroup per CU); the default of the SEARCH path (shim, CLI, batch) since round 4, "
+                    "`value` stays the FIR mode"}
 
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
         scorer.set_reference(ref)

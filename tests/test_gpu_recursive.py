@@ -151,9 +151,8 @@ def test_4k_search_in_both_blur_modes_records_the_quantizers(hip_lib, tmp_path):
     nothing about the agreement itself can be asserted; what is asserted: both searches finish
     inside the pass budget, the two modes' scores of one probe differ by less than the recursion's
     known 4K noise envelope (3 points), and the cached-reference pass the search runs returns the
-    pair score's bits in either mode.  The record goes to gpurun_out/ when that is writable."""
-    import json
-    import os
+    pair score's bits in either mode.  (The 24-search record with every search's quantizers is made by
+    tests/tools/gpu_blur_mode_gap.py --json: profiles/r04_4k_search_both_modes.json.)"""
 
     from oavif_amd import Ssimu2, tq
     if not synth.have_avif():
@@ -183,9 +182,6 @@ def test_4k_search_in_both_blur_modes_records_the_quantizers(hip_lib, tmp_path):
                            "passes_fir": a.num_pass, "passes_recursive": b.num_pass,
                            "first_probe_q": q0, "first_probe_dscore": d0})
     print("4K searches, FIR vs recursive:", record)
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    if os.path.isdir(out) and os.access(out, os.W_OK):
-        json.dump(record, open(os.path.join(out, "r03_4k_search_both_modes.json"), "w"), indent=1)
 
 
 def test_env_selects_the_mode_for_cli_and_batch(hip_lib, monkeypatch, rscorer):
