@@ -106,3 +106,63 @@ def test_round3_fields_repeated_timing_and_the_recursive_modes_pass():
     assert r["cached_reference"]["ms_per_pass"] <= 0.5 < 2 * r["ms_per_score"]
     assert r["device_memory_MB"]["reference_cache"] + r["device_memory_MB"]["per_pass_scratch"] < 1000
     assert d["roofline"]["counters"]["stale"] is False
+
+
+def test_round4_fields_cpu_baseline_placement_record_and_two_context_ratio():
+    """the CPU baseline carries what decides it (quota, candidate slices with their
+    probe rates, the chosen slice and its busy fractions, per-repetition min / median, throttle count) and is the
+    rate of the MEDIAN repetition; the stream-overlap figure is a reported number with the placed-set size."""
+    d = _line()
+    c = d["cpu_baseline"]
+    p = c["placement"]
+    assert p["cgroup_cpu_quota"] and p["affinity_cpus"] >= c["cores"]
+    assert len(p["candidates"]) >= 1 and all("cpus" in k for k in p["candidates"])
+    assert p["chosen"] == c["pinned_to_cpus"] and len(p["busy_fraction_of_chosen_before"]) == c["cores"]
+    reps = p["ms_per_rep"]
+    assert reps["n"] >= 10 and reps["min"] <= reps["median"] <= reps["max"]
+    mp = d["config"]["width"] * d["config"]["height"] / 1e6
+    assert abs(c["value"] - mp / reps["median"] * 1e3) / c["value"] < 2e-3
+    assert c["value"] <= c["value_best_rep"]
+    # the fixed slice is kept unless another one probed > 10 % faster
+    rates = [k["MPps_best_of_2"] for k in p["candidates"] if "MPps_best_of_2" in k]
+    assert p["chosen_is_fixed_slice"] == (max(rates) <= 1.10 * rates[0])
+    t = d["two_context_ratio"]
+    assert 0.5 < t["value"] < 1.0 and t["placed_streams"] >= 2
+    assert abs(t["value"] - t["ms_per_score_two_contexts"] / t["ms_per_score_one_context"]) < 2e-3
+
+
+def test_cpu_baseline_keeps_the_fixed_slice_unless_another_is_clearly_faster(monkeypatch):
+    """bench.measure_cpu_baseline with the child processes scripted: candidate slices are probed in order, the
+    rank's fixed slice is kept unless another one is > 10 % faster, the full sample runs on the chosen slice and
+    `value` is the median repetition."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oavif_amd import hostinfo
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 4.0)
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(16)))
+    monkeypatch.setattr(hostinfo, "candidate_core_sets", lambda n, max_sets=3: [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]])
+    monkeypatch.setattr(hostinfo, "busy_fractions", lambda cpus, s=1.0, **k: {c: 0.0 for c in cpus})
+    monkeypatch.setattr(bench, "usable_cores", lambda: 4)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    calls = []
+
+    def fake_child(rates):
+        def run(cpus, threads, w, h, seconds, maxreps):
+            calls.append((tuple(cpus), seconds))
+            ms = 1000.0 * 8.2944 / rates[tuple(cpus)]
+            reps = [ms] * 2 if seconds == 0.0 else [ms * f for f in (1.0, 1.3, 0.9, 1.1, 1.0)]
+            return {"threads": threads, "ms": reps, "score": 60.0, "pin_error": "", "build": "fake", "single_thread_MPps": 3.0}
+        return run
+    # a second slice 8 % faster: the fixed slice stays
+    monkeypatch.setattr(bench, "run_cpu_child", fake_child({(0, 1, 2, 3): 50.0, (4, 5, 6, 7): 54.0, (8, 9, 10, 11): 40.0}))
+    cb = bench.measure_cpu_baseline(3840, 2160, 8.2944)
+    assert cb["pinned_to_cpus"] == "0-3" and cb["placement"]["chosen_is_fixed_slice"] and calls[-1] == ((0, 1, 2, 3), 12.0)
+    assert abs(cb["value"] - 50.0) < 0.01 and cb["cores"] == 4 and abs(cb["value_best_rep"] - 50.0 / 0.9) < 0.01
+    # the fixed slice shared with another tenant (20 MP/s): the clearly faster slice is taken, and said so
+    calls.clear()
+    monkeypatch.setattr(bench, "run_cpu_child", fake_child({(0, 1, 2, 3): 20.0, (4, 5, 6, 7): 54.0, (8, 9, 10, 11): 40.0}))
+    cb = bench.measure_cpu_baseline(3840, 2160, 8.2944)
+    assert cb["pinned_to_cpus"] == "4-7" and not cb["placement"]["chosen_is_fixed_slice"] and calls[-1] == ((4, 5, 6, 7), 12.0)
+    assert [k["cpus"] for k in cb["placement"]["candidates"]] == ["0-3", "4-7", "8-11"]
