@@ -493,17 +493,6 @@ void rg_build_plan(const ssimu2_ctx* c, const Pyramid& p, bool ref_frame, RgPlan
     *vblocks = vb_;
 }
 
-// Experiment knob of the instrumented build (always 0 in the product): dynamic LDS added to a
-// recursive-mode launch, which caps the workgroups a CU takes at once.
-#ifdef SSIMU2_INSTRUMENTED_BUILD
-static int rg_extra_lds(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-#else
-static int rg_extra_lds(const char*) { return 0; }
-#endif
-
 // Instrumented builds (ssimu2_instr_rg_stop_after_scale): keep the raw planes of one scale for the
 // parity tests.  After a horizontal pass its planes are copied out of hbuf; the per-pass planes of
 // the vertical pass exist only in LDS, so k_rg_v_emit recomputes them into the debug buffer.

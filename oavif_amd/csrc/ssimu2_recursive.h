@@ -10,8 +10,9 @@
 // reproduced bit for bit -- so whichever form fssimu2 follows can be had on the device.
 //
 // A recursion cannot be cut into strips or segments: every output depends on the whole line
-// before it, so the parallelism is lines x planes x sections and nothing else.  Round 3 layout
-// (all six scales in ONE launch per stage, largest scale first):
+// before it, so the parallelism is lines x planes x sections and nothing else.  Layout since round 3
+// (all six scales in ONE launch per stage, largest scale first; round 4: rows of every plane padded to
+// 128 floats, products formed once in k_rg_h's staging, k_rg_v persistent with one workgroup per CU):
 //
 //   k_pyramid_bands_xyb (ssimu2_kernels.h)  positive-XYB planes of one frame at every scale,
 //              straight from its bytes: the band pyramid with XYB outputs, no linear level stored.
@@ -21,9 +22,9 @@
 //              planes of one channel over the same 20 rows, one wave per plane ({y, yy, xy} of
 //              a pass, {x, xx} of the reference), so the shared inputs are fetched once.  Each
 //              wave stages its 20 rows 64 columns at a time through wave-private LDS with coalesced
-//              16-byte loads and stores (see "Staging" below); products are formed on the way in,
-//              rounded to fp32 first as published.  7 VALU instructions per step (8 for a product
-//              plane) instead of 15.
+//              16-byte loads and stores (see "Staging" below); products are formed once per element
+//              while the tile is staged, rounded to fp32 first as published.  7 VALU instructions per
+//              step instead of 15.
 //   k_rg_v     vertical pass + maps.  lane = image column (coalesced rows), the three sections in
 //              the lane; batches of ten rows, so that the left-hand inputs of a batch are the
 //              right-hand ones of the previous batch; loads three batches ahead, streaming
@@ -31,7 +32,8 @@
 //              rows go to a double-buffered LDS tile, where five more waves of the workgroup
 //              turn them -- with the cached reference planes -- into the SSIM / edge-difference
 //              sums (the expressions of k_march): the nine per-pass planes never reach HBM after
-//              the vertical pass.
+//              the vertical pass.  Persistent: one workgroup per CU pulls (scale, channel, column
+//              group) jobs longest first (see the kernel).
 //   reference  mu1 = blur(x) and s11 = blur(x*x) depend on the reference alone (tq.zig:37 passes
 //              the same e.rgb on every pass): ssimu2_set_reference runs both passes over {x, xx}
 //              once and keeps the planes, so a pass of a search recurses 9 planes, not 15.

@@ -19,7 +19,8 @@ print("""# Round 4: what bounds the recursive-mode kernels at 3840x2160 (one ref
 #   h_nostore   k_rg_h without its global stores        h_sametile  k_rg_h loading tile 0 over and over (cache-fed)
 #   h_chain     both: no HBM traffic at all             v_samerows  k_rg_v loading rows 0-9 over and over (cache-fed)
 #   v_reverse   k_rg_v column groups right to left      h_ntld      nontemporal loads in k_rg_h
-#   OAVIF_RG_LDS_H / _V = N   N bytes of dynamic LDS added to the launch: one workgroup per CU
+#   OAVIF_RG_LDS_H / _V = N   N bytes of dynamic LDS added to the launch: one workgroup per CU (a knob of the
+#               instrumented build at that commit; the persistent k_rg_v made it permanent, the knob is gone)
 #   p_*         the PERSISTENT k_rg_h (one 8-wave workgroup per CU, two job queues, class by SIMD):
 #               p_chain / p_nostore / p_sametile as above; p_chain_long = only the long class (972 full-resolution
 #               chains + 52, one per SIMD) without HBM; p_chain_fill = only the filler class; p_long = long class, HBM-fed

@@ -25,8 +25,8 @@ def _ms_per_score(group, pr, pd, w, h, n=240):
 def test_contexts_created_back_to_back_get_distinct_queues(hip_lib):
     """What is ASSERTED is collision detection, not a margin: (i) the placed set holds at least two streams
     (three with HIP's default of four hardware queues: one is the null stream's) -- asked of the instrumented
-    library instance, which runs the same placement code; (ii) every pair among three product contexts created
-    back to back scores faster on two contexts than 0.95 x the one-context time per score (a pair that shares
+    library instance, which runs the same placement code; (ii) every pair among as many product contexts as the
+    placed set has members (created back to back) scores faster on two contexts than 0.95 x the one-context time per score (a pair that shares
     a hardware queue measures 1.0; pairs on distinct queues 0.87-0.89, best of four runs each).  The ratio
     itself is a reported number -- bench.py's `two_context_ratio` -- not a test criterion: it varies by ~0.03
     between boxes of the pool (round 3's 0.9 assert sat 1-3 % from the measured values)."""
@@ -41,18 +41,18 @@ def test_contexts_created_back_to_back_get_distinct_queues(hip_lib):
         placed = probe.placed_streams()
     print(f"placed streams on distinct hardware queues: {placed}")
     assert placed >= 2, placed
-    ctx = [Ssimu2(0) for _ in range(3)]
+    n = min(placed, 4)   # every member of the placed set is checked against every other: the probe's own verdicts
+    ctx = [Ssimu2(0) for _ in range(n)]
     try:
         _ms_per_score(ctx[:2], pr, pd, w, h, 600)   # clocks
         one = min(_ms_per_score([c], pr, pd, w, h) for c in ctx for _ in range(2))
-        for i in range(3):
-            for j in range(i + 1, 3):
+        for i in range(n):
+            for j in range(i + 1, n):
                 two = min(_ms_per_score([ctx[i], ctx[j]], pr, pd, w, h) for _ in range(4))
                 print(f"contexts {i},{j}: {two:.4f} ms per score on two, {one:.4f} on one, ratio {two / one:.3f}")
-                if placed >= 3 or (i, j) == (0, 1):
-                    assert two <= 0.95 * one, (i, j, two, one)
+                assert two <= 0.95 * one, (i, j, two, one)
         # the scores do not depend on the stream
-        a, b = ctx[0].score_device(pr, pd, w, h), ctx[2].score_device(pr, pd, w, h)
+        a, b = ctx[0].score_device(pr, pd, w, h), ctx[n - 1].score_device(pr, pd, w, h)
         assert a == b
     finally:
         for c in ctx:
