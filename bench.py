@@ -503,7 +503,9 @@ def main() -> int:
             out["two_context_ratio"] = {"value": round(out["ms_per_step"] / score_ms, 3),
                                         "ms_per_score_two_contexts": out["ms_per_step"],
                                         "ms_per_score_one_context": round(score_ms, 5),
-                                        "placed_streams": iscorer.placed_streams()}
+                                        "placed_streams": iscorer.placed_streams(),
+                                        "placed_streams_note": "size of the placed set of the INSTRUMENTED library instance of this "
+                                                               "process (same placement code as the product instance, its own probe)"}
         iscorer.close()
 
         # ---- the search's per-pass score: reference cached on the device (tq.zig:37 passes the
