@@ -25,8 +25,8 @@ def _ms_per_score(group, pr, pd, w, h, n=240):
 def test_contexts_created_back_to_back_get_distinct_queues(hip_lib):
     """What is ASSERTED is collision detection, not a margin: (i) the placed set holds at least two streams
     (three with HIP's default of four hardware queues: one is the null stream's) -- asked of the instrumented
-    library instance, which runs the same placement code; (ii) every pair among as many product contexts as the
-    placed set has members (created back to back) scores faster on two contexts than 0.95 x the one-context time per score (a pair that shares
+    library instance, which runs the same placement code; (ii) every pair among three product contexts created
+    back to back scores faster on two contexts than 0.95 x the one-context time per score (a pair that shares
     a hardware queue measures 1.0; pairs on distinct queues 0.87-0.89, best of four runs each).  The ratio
     itself is a reported number -- bench.py's `two_context_ratio` -- not a test criterion: it varies by ~0.03
     between boxes of the pool (round 3's 0.9 assert sat 1-3 % from the measured values)."""
@@ -41,7 +41,10 @@ def test_contexts_created_back_to_back_get_distinct_queues(hip_lib):
         placed = probe.placed_streams()
     print(f"placed streams on distinct hardware queues: {placed}")
     assert placed >= 2, placed
-    n = min(placed, 4)   # every member of the placed set is checked against every other: the probe's own verdicts
+    # three product contexts: the documented contract is "any two of the first three contexts of a process overlap"
+    # (INTEGRATION.md section 5); the product instance's own set may be smaller than the instrumented instance's
+    # (each instance probes for itself; with HIP's four hardware queues a fourth context may share one)
+    n = 3 if placed >= 3 else 2
     ctx = [Ssimu2(0) for _ in range(n)]
     try:
         _ms_per_score(ctx[:2], pr, pd, w, h, 600)   # clocks
