@@ -828,6 +828,29 @@ __device__ __forceinline__ void march_v(const lds_vu64* rp, float (&win)[5][9], 
     acc[5] += t2 * t2;
 }
 
+// XCD-aware tile order.  Workgroups are dealt to the eight XCDs round-robin by blockIdx (each XCD has its own
+// 4 MiB L2), while neighbouring strips of one segment share their 8 halo columns and -- strips being 120 columns,
+// not a multiple of a 128-byte line -- the cache lines their edges straddle.  With tile = blockIdx those neighbours
+// sit on DIFFERENT XCDs and every XCD fetches its own copy.  MARCH_XCD_ORDER = 1 hands each XCD a contiguous run of
+// tiles instead: among the workgroups [first, end) of a scale, the ones with blockIdx % 8 == x take the x-th run,
+// in blockIdx order.  A bijection on [0, end - first); which workgroup computes a tile does not enter the tile's
+// arithmetic, and the partial sums are stored under the TILE index: scores keep their bits.
+#ifndef MARCH_XCD_ORDER
+#define MARCH_XCD_ORDER 1
+#endif
+__device__ __forceinline__ int march_tile_of_block(int b, int first, int end) {
+    if (!MARCH_XCD_ORDER) return b - first;
+    // cnt(n, r) = how many k in [0, n) have k % 8 == r
+    const int x = b & 7;
+    int before = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n_r = (end + 7 - r) / 8 - (first + 7 - r) / 8;  // workgroups of this scale on XCD phase r
+        before += r < x ? n_r : 0;
+    }
+    return before + (b >> 3) - ((first + 7 - x) >> 3);  // + its rank among those of phase x
+}
+
 template <int MODE>
 __device__ __forceinline__ void march_body(const MarchPlan& plan) {
     // [row slot][channel][column] of (ref, dist) pairs
@@ -845,7 +868,7 @@ __device__ __forceinline__ void march_body(const MarchPlan& plan) {
             sc = s + 1;
             first = plan.blk_end[s];
         }
-    const int blk = (int)blockIdx.x - first;
+    const int blk = march_tile_of_block((int)blockIdx.x, first, plan.blk_end[sc]);
     const int w = plan.w[sc], h = plan.h[sc], seg_rows = plan.seg[sc];
     const int nstrips = plan.nstrips[sc];
     const int by = blk / nstrips, bx = blk - by * nstrips;
