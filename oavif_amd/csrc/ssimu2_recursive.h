@@ -333,8 +333,9 @@ __host__ __device__ __forceinline__ int rg_plane15(bool ref, int ch, int kind) {
 // What bounds it (round 4, profiles/r04_rg_chain_vs_bytes.log, 4K pass): with every HBM access taken
 // away the launch takes 139 us (a wave alone on a SIMD needs 26 ns per step, 101 us for a 3,840-step
 // row; some SIMDs hold two full-resolution waves), with only its loads or only its stores coming from
-// HBM 144-152 us, with both 173-177 us: 0.70 GB of interleaved reads and writes at 4.0 TB/s, which is
-// what a mixed read + write stream reaches on this chip (the conversion kernel, 84 % writes: 4.4 TB/s).
+// HBM 144-152 us, with both 159-177 us: 0.70 GB of interleaved reads and writes at 4.0-4.4 TB/s, 0.85 of
+// the 5.1 TB/s a clean 2 : 3 read + write stream reaches on this chip (profiles/r04_rw_mix.txt) -- and
+// at that ceiling the bytes alone would take 137 us, the same as the chains alone: both floors coincide.
 // A persistent form that gives every full-resolution chain a SIMD of its own (RG_H_PERSISTENT = 1:
 // one workgroup of eight waves per CU, jobs handed out longest first through two cursors, the class
 // of a wave decided by the SIMD it finds itself on) has the same 137 us without HBM and 206-222 us
