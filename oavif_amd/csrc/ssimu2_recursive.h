@@ -241,7 +241,19 @@ __device__ __forceinline__ void rg_h_store(const RgLine& L, const RgRing& tout, 
     }
 }
 
-template <bool FMA, int OPK, bool EDGE>
+// AHEAD: tiles the global loads run ahead of their use (1, or 2 with two register sets).  Measured (round 4,
+// profiles/r04_rg_ahead_ab.log): two tiles ahead take the REFERENCE's horizontal pass (planes x, x*x; two waves per
+// workgroup; 238 VGPRs, no spill) from 134 to 124 us.  The pass kernel gets SLOWER with it: its x*y plane needs 80
+// registers for two sets and spills under the 256-register cap of two waves per SIMD (171 us against 163), and with
+// only the one-plane jobs two ahead it is still 171 -- three waves per workgroup already keep the memory system
+// at 0.85 of what a mixed stream reaches, more loads in flight only lengthen the queue.  So: 2 for the reference, 1 for a pass.
+#ifndef RG_H_AHEAD_REF
+#define RG_H_AHEAD_REF 2
+#endif
+#ifndef RG_H_AHEAD_PASS
+#define RG_H_AHEAD_PASS 1
+#endif
+template <bool FMA, int OPK, bool EDGE, int AHEAD>
 __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin, RgRing& tout, float* dump,
                                           rg_f4 (&ra)[RG_TR], rg_f4 (&rb)[RG_TR], int T) {
     const int rr = threadIdx.x >> 4 & 3, cc = threadIdx.x & 15;
@@ -258,7 +270,7 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin, RgRing& tout, 
         }
         *reinterpret_cast<rg_f4*>(&tin[4 * i + rr][4 * cc]) = v;
     }
-    rg_h_fetch<OPK>(L, ra, rb, T + 1);  // lands under this tile's 64 steps
+    rg_h_fetch<OPK>(L, ra, rb, T + AHEAD);  // lands under the steps of this tile (and of the next, AHEAD = 2)
     __builtin_amdgcn_wave_barrier();
     // 16 columns at a time; the LDS reads of the next 16 are issued before the steps of these 16
     // (an LDS read takes ~100+ cycles to land)
@@ -300,23 +312,46 @@ __device__ __forceinline__ void rg_h_tile(RgLine& L, RgTile& tin, RgRing& tout, 
     if (T > 0) rg_h_store<EDGE>(L, tout, T - 1);  // uniform; segment T - 1 is complete now
 }
 
-template <bool FMA, int OPK>
+template <bool FMA, int OPK, int AHEAD>
 __device__ __forceinline__ void rg_h_line(RgLine& L, RgTile& tin, RgRing& tout, float* dump) {
     const int w = L.w;
     const int ntiles = (w + (RG_N - 1) + RG_TW - 1) / RG_TW;  // steps run to m = w + 3
     // tiles 1 .. nmain - 1 lie inside the row and complete a segment that does (64 (T + 1) <= w)
     const int nmain = max(1, w / RG_TW);
-    rg_f4 ra[RG_TR], rb[RG_TR];
 #pragma unroll
     for (int k = 0; k < RG_HT; ++k) L.cur[1][k] = 0.0f;  // columns -16 .. -1
     L.p1 = L.p2 = 0.0f;
-    rg_h_fetch<OPK>(L, ra, rb, 0);
-    rg_h_tile<FMA, OPK, true>(L, tin, tout, dump, ra, rb, 0);
-    int T = 1;
+    if constexpr (AHEAD == 1) {
+        rg_f4 ra[RG_TR], rb[RG_TR];
+        rg_h_fetch<OPK>(L, ra, rb, 0);
+        rg_h_tile<FMA, OPK, true, 1>(L, tin, tout, dump, ra, rb, 0);
+        int T = 1;
 #pragma unroll 1
-    for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false>(L, tin, tout, dump, ra, rb, T);
+        for (; T < nmain; ++T) rg_h_tile<FMA, OPK, false, 1>(L, tin, tout, dump, ra, rb, T);
 #pragma unroll 1
-    for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true>(L, tin, tout, dump, ra, rb, T);
+        for (; T < ntiles; ++T) rg_h_tile<FMA, OPK, true, 1>(L, tin, tout, dump, ra, rb, T);
+    } else {
+        // two register sets: tile T is staged from set T & 1, which is then refilled with tile T + 2
+        rg_f4 ra0[RG_TR], rb0[RG_TR], ra1[RG_TR], rb1[RG_TR];
+        rg_h_fetch<OPK>(L, ra0, rb0, 0);
+        rg_h_fetch<OPK>(L, ra1, rb1, 1);
+        rg_h_tile<FMA, OPK, true, 2>(L, tin, tout, dump, ra0, rb0, 0);
+        int T = 1;
+#pragma unroll 1
+        for (; T + 1 < nmain; T += 2) {  // T odd here
+            rg_h_tile<FMA, OPK, false, 2>(L, tin, tout, dump, ra1, rb1, T);
+            rg_h_tile<FMA, OPK, false, 2>(L, tin, tout, dump, ra0, rb0, T + 1);
+        }
+        if (T < nmain) {  // uniform
+            rg_h_tile<FMA, OPK, false, 2>(L, tin, tout, dump, ra1, rb1, T);
+            ++T;
+        }
+#pragma unroll 1
+        for (; T < ntiles; ++T) {
+            if (T & 1) rg_h_tile<FMA, OPK, true, 2>(L, tin, tout, dump, ra1, rb1, T);
+            else rg_h_tile<FMA, OPK, true, 2>(L, tin, tout, dump, ra0, rb0, T);
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     rg_h_store<true>(L, tout, ntiles - 1);  // the row's last columns (w - 1 <= 64 (ntiles - 1) + 59)
 }
@@ -419,14 +454,15 @@ __global__ __launch_bounds__(64 * RG_HW) void k_rg_h_persistent(RgPlan p) {
         // REF: x, x*x.  pass: y, y*y, x*y
         L.ga = kind == 2 ? xa : xb;
         L.gb = xb;
-        if (kind == 0) rg_h_line<FMA, 0>(L, s_in[wave], s_o[wave], s_dump);
-        else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[wave], s_o[wave], s_dump);
-        else rg_h_line<FMA, 2>(L, s_in[wave], s_o[wave], s_dump);
+        constexpr int AHEAD = REF ? RG_H_AHEAD_REF : RG_H_AHEAD_PASS;
+        if (kind == 0) rg_h_line<FMA, 0, AHEAD>(L, s_in[wave], s_o[wave], s_dump);
+        else if (kind == 1) rg_h_line<FMA, 1, AHEAD>(L, s_in[wave], s_o[wave], s_dump);
+        else rg_h_line<FMA, 2, AHEAD>(L, s_in[wave], s_o[wave], s_dump);
     }
 }
 
 template <bool FMA, bool REF>
-__global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (capped at 168 VGPRs for 3 waves per SIMD it spills and is slower)
+__global__ __launch_bounds__(REF ? 128 : 192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rg_h(RgPlan p) {  // (capped at 168 VGPRs for 3 waves per SIMD it spills and is slower)
     constexpr int NK = REF ? 2 : 3;
     __shared__ __attribute__((aligned(16))) RgTile s_in[NK];
     __shared__ __attribute__((aligned(16))) RgRing s_o[NK];
@@ -464,9 +500,10 @@ __global__ __launch_bounds__(REF ? 128 : 192) void k_rg_h(RgPlan p) {  // (cappe
     // REF: x, x*x.  pass: y, y*y, x*y
     L.ga = kind == 2 ? xa : xb;
     L.gb = xb;
-    if (kind == 0) rg_h_line<FMA, 0>(L, s_in[0], s_o[0], s_dump);
-    else if (kind == 1) rg_h_line<FMA, 1>(L, s_in[1], s_o[1], s_dump);
-    else rg_h_line<FMA, 2>(L, s_in[NK - 1], s_o[NK - 1], s_dump);
+    constexpr int AHEAD = REF ? RG_H_AHEAD_REF : RG_H_AHEAD_PASS;
+    if (kind == 0) rg_h_line<FMA, 0, AHEAD>(L, s_in[0], s_o[0], s_dump);
+    else if (kind == 1) rg_h_line<FMA, 1, AHEAD>(L, s_in[1], s_o[1], s_dump);
+    else rg_h_line<FMA, 2, AHEAD>(L, s_in[NK - 1], s_o[NK - 1], s_dump);
 }
 
 // ---- vertical pass (+ maps) -----------------------------------------------------------------------
