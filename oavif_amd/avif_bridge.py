@@ -1,0 +1,423 @@
+"""libavif's C API, called the way the reference calls it (io.zig:452-482, 544-666).
+
+SURVEY.md rows A10 / A11 keep the AVIF encode and decode on the CPU, unchanged, in libavif (aom / dav1d).
+The build image has no libavif headers, so the C++ side cannot include <avif/avif.h>; it does have a
+libavif 1.4.1 shared library (the one Pillow bundles under pillow.libs/, aom 3.13.2 + dav1d 1.5.3).
+Pillow's own plugin reaches only part of it (8-bit, no `tune=iq`, no CICP, no alpha quality), which is why
+rounds 1-3 could not honour `--tenbit 1` (the reference's default, parse_args.zig:56).  This module binds
+the library's C entry points directly with ctypes and makes the same sequence of calls with the same
+arguments as the reference:
+
+    encode   avifImageCreate(w, h, 8|10, YUV444) -> CICP -> avifImageSetProfileICC -> avifRGBImageSetDefaults
+             -> format / pixels / rowBytes / depth -> avifImageRGBToYUV -> avifEncoderCreate -> copyToEncoder
+             (qualityAlpha, speed, maxThreads, tile*Log2, autoTiling, codec option "tune") -> quality = q
+             -> avifEncoderAddImage(.., 1, SINGLE) -> avifEncoderFinish                 io.zig:544-636
+    decode   avifDecoderCreate -> SetIOMemory -> Parse -> NextImage -> avifRGBImageSetDefaults -> depth = 8
+             -> RGBA iff the image has an alpha plane -> AllocatePixels -> avifImageYUVToRGB -> tight RGB8,
+             alpha dropped                                                               io.zig:452-482,638-666
+
+The struct layouts (avifImage, avifRGBImage, avifEncoder, avifDecoder) are written out below from the
+public header of libavif 1.x, and **checked against the loaded library before anything is encoded**: the
+documented defaults of avifEncoderCreate / avifDecoderCreate / avifImageCreate / avifRGBImageSetDefaults
+form a signature (maxThreads 1, speed -1, timescale 1, quantizers 0..63, size limits, CICP 2/2/2, ...) that
+is read back through these offsets.  A library whose layout differs fails the check and `available()` is
+False: callers then fall back to Pillow's plugin and say so (8-bit only).  Host code; no GPU involved.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import os
+import struct
+import threading
+from typing import Optional
+
+import numpy as np
+
+# avif.h enumerators used here
+_PIXEL_FORMAT_YUV444 = 1
+_RGB_FORMAT_RGB, _RGB_FORMAT_RGBA = 0, 1
+_ADD_IMAGE_FLAG_SINGLE = 2
+_RESULT_OK = 0
+
+# offsets into the public structs of libavif 1.x (x86-64); verified by _check_layout()
+_IMG_WIDTH, _IMG_HEIGHT, _IMG_DEPTH, _IMG_YUVFORMAT, _IMG_YUVRANGE = 0, 4, 8, 12, 16
+_IMG_ALPHAPLANE = 64
+_IMG_ICC = 88               # avifRWData {data, size}
+_IMG_CP, _IMG_TC, _IMG_MC = 104, 106, 108   # uint16_t each
+_RGB_SIZE = 64
+_RGB_DEPTH, _RGB_FORMAT, _RGB_MAXTHREADS, _RGB_PIXELS, _RGB_ROWBYTES = 8, 12, 40, 48, 56
+_ENC_MAXTHREADS, _ENC_SPEED, _ENC_QUALITY, _ENC_QUALITYALPHA = 4, 8, 32, 36
+_ENC_TILEROWS, _ENC_TILECOLS, _ENC_AUTOTILING = 56, 60, 64
+_DEC_IMAGE = 48
+
+
+class AvifBridgeError(Exception):
+    """Carries the reference's Zig error name (io.zig) and libavif's own message."""
+
+    def __init__(self, name: str, detail: str = ""):
+        super().__init__(f"{name}: {detail}" if detail else name)
+        self.name = name
+
+
+class _RWData(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("size", ctypes.c_size_t)]
+
+
+_lock = threading.Lock()
+_state = {"lib": None, "why": None, "path": None}
+
+
+def _find_library() -> Optional[str]:
+    p = os.environ.get("OAVIF_LIBAVIF")
+    if p:
+        return p
+    try:
+        import PIL
+    except ImportError:
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(PIL.__file__)))
+    hits = sorted(glob.glob(os.path.join(root, "pillow.libs", "libavif*.so*")))
+    return hits[0] if hits else None
+
+
+def _bind(L) -> None:
+    vp, u32, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
+    L.avifVersion.restype = ctypes.c_char_p
+    L.avifResultToString.argtypes, L.avifResultToString.restype = [ci], ctypes.c_char_p
+    L.avifCodecVersions.argtypes, L.avifCodecVersions.restype = [ctypes.c_char_p], None
+    L.avifImageCreate.argtypes, L.avifImageCreate.restype = [u32, u32, u32, ci], vp
+    L.avifImageDestroy.argtypes, L.avifImageDestroy.restype = [vp], None
+    L.avifImageSetProfileICC.argtypes, L.avifImageSetProfileICC.restype = [vp, ctypes.c_char_p, ctypes.c_size_t], ci
+    L.avifRGBImageSetDefaults.argtypes, L.avifRGBImageSetDefaults.restype = [vp, vp], None
+    L.avifRGBImageAllocatePixels.argtypes, L.avifRGBImageAllocatePixels.restype = [vp], ci
+    L.avifRGBImageFreePixels.argtypes, L.avifRGBImageFreePixels.restype = [vp], None
+    L.avifImageRGBToYUV.argtypes, L.avifImageRGBToYUV.restype = [vp, vp], ci
+    L.avifImageYUVToRGB.argtypes, L.avifImageYUVToRGB.restype = [vp, vp], ci
+    L.avifEncoderCreate.argtypes, L.avifEncoderCreate.restype = [], vp
+    L.avifEncoderDestroy.argtypes, L.avifEncoderDestroy.restype = [vp], None
+    L.avifEncoderSetCodecSpecificOption.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.avifEncoderSetCodecSpecificOption.restype = ci
+    L.avifEncoderAddImage.argtypes, L.avifEncoderAddImage.restype = [vp, vp, ctypes.c_uint64, u32], ci
+    L.avifEncoderFinish.argtypes, L.avifEncoderFinish.restype = [vp, ctypes.POINTER(_RWData)], ci
+    L.avifRWDataFree.argtypes, L.avifRWDataFree.restype = [ctypes.POINTER(_RWData)], None
+    L.avifDecoderCreate.argtypes, L.avifDecoderCreate.restype = [], vp
+    L.avifDecoderDestroy.argtypes, L.avifDecoderDestroy.restype = [vp], None
+    L.avifDecoderSetIOMemory.argtypes, L.avifDecoderSetIOMemory.restype = [vp, ctypes.c_char_p, ctypes.c_size_t], ci
+    L.avifDecoderParse.argtypes, L.avifDecoderParse.restype = [vp], ci
+    L.avifDecoderNextImage.argtypes, L.avifDecoderNextImage.restype = [vp], ci
+
+
+def _i32(addr: int, off: int) -> int:
+    return ctypes.c_int32.from_address(addr + off).value
+
+
+def _u32(addr: int, off: int) -> int:
+    return ctypes.c_uint32.from_address(addr + off).value
+
+
+def _u16(addr: int, off: int) -> int:
+    return ctypes.c_uint16.from_address(addr + off).value
+
+
+def _ptr(addr: int, off: int) -> int:
+    return ctypes.c_void_p.from_address(addr + off).value or 0
+
+
+def _check_layout(L) -> Optional[str]:
+    """None if the loaded library lays its public structs out as this module assumes; else what differs."""
+    ver = L.avifVersion().decode()
+    if not ver.startswith("1."):
+        return f"libavif {ver}: layouts here are those of 1.x"
+    enc = L.avifEncoderCreate()
+    if not enc:
+        return "avifEncoderCreate failed"
+    try:
+        words = [_i32(enc, 4 * i) for i in range(21)]
+    finally:
+        L.avifEncoderDestroy(enc)
+    # codecChoice, maxThreads, speed, keyframeInterval, timescale (u64), repetitionCount, extraLayerCount,
+    # quality, qualityAlpha, min/maxQuantizer, min/maxQuantizerAlpha, tileRowsLog2, tileColsLog2, autoTiling,
+    # scalingMode {1/1, 1/1}
+    want = [0, 1, -1, 0, 1, 0, -1, 0, None, None, 0, 63, 0, 63, 0, 0, 0, 1, 1, 1, 1]
+    if any(w is not None and w != g for w, g in zip(want, words)):
+        return f"avifEncoder defaults {words} do not match the 1.x layout"
+    dec = L.avifDecoderCreate()
+    if not dec:
+        return "avifDecoderCreate failed"
+    try:
+        dw = [_u32(dec, 4 * i) for i in range(11)]
+        img_before = _ptr(dec, _DEC_IMAGE)
+    finally:
+        L.avifDecoderDestroy(dec)
+    # codecChoice, maxThreads, requestedSource, allowProgressive, allowIncremental, ignoreExif, ignoreXMP,
+    # imageSizeLimit 16384^2, imageDimensionLimit 32768, imageCountLimit 12 h at 60 fps, strictFlags
+    if dw[:10] != [0, 1, 0, 0, 0, 0, 0, 16384 * 16384, 32768, 12 * 3600 * 60] or img_before != 0:
+        return f"avifDecoder defaults {dw} do not match the 1.x layout"
+    im = L.avifImageCreate(24, 16, 10, _PIXEL_FORMAT_YUV444)
+    if not im:
+        return "avifImageCreate failed"
+    try:
+        head = (_u32(im, _IMG_WIDTH), _u32(im, _IMG_HEIGHT), _u32(im, _IMG_DEPTH), _u32(im, _IMG_YUVFORMAT),
+                _u32(im, _IMG_YUVRANGE))
+        cicp = (_u16(im, _IMG_CP), _u16(im, _IMG_TC), _u16(im, _IMG_MC))
+        if head != (24, 16, 10, 1, 1) or cicp != (2, 2, 2) or _ptr(im, _IMG_ALPHAPLANE) != 0 \
+                or _ptr(im, _IMG_ICC) != 0:
+            return f"avifImage fields {head} {cicp} do not match the 1.x layout"
+        icc = b"layout-check"
+        if L.avifImageSetProfileICC(im, icc, len(icc)) != _RESULT_OK:
+            return "avifImageSetProfileICC failed"
+        if ctypes.c_size_t.from_address(im + _IMG_ICC + 8).value != len(icc) or \
+                ctypes.string_at(_ptr(im, _IMG_ICC), len(icc)) != icc:
+            return "avifImage.icc is not where the 1.x layout puts it"
+        rgb = ctypes.create_string_buffer(b"\xaa" * 128, 128)
+        L.avifRGBImageSetDefaults(rgb, im)
+        got = struct.unpack_from("<11i", rgb.raw, 0) + struct.unpack_from("<QI", rgb.raw, _RGB_PIXELS)
+        # width, height, depth, format RGBA, chroma up / down, avoidLibYUV, ignoreAlpha, alphaPremultiplied,
+        # isFloat, maxThreads, pixels, rowBytes; nothing written beyond 60 bytes
+        if got != (24, 16, 10, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0) or rgb.raw[60:] != b"\xaa" * 68:
+            return f"avifRGBImage defaults {got} do not match the 1.x layout"
+        if L.avifRGBImageAllocatePixels(rgb) != _RESULT_OK:
+            return "avifRGBImageAllocatePixels failed"
+        pix, row = struct.unpack_from("<QI", rgb.raw, _RGB_PIXELS)
+        L.avifRGBImageFreePixels(rgb)
+        if not pix or row != 24 * 4 * 2:
+            return f"avifRGBImage.pixels / rowBytes ({pix:#x}, {row}) are not where the 1.x layout puts them"
+    finally:
+        L.avifImageDestroy(im)
+    return None
+
+
+def _lib():
+    with _lock:
+        if _state["lib"] is None and _state["why"] is None:
+            path = _find_library()
+            if path is None:
+                _state["why"] = "no libavif shared library found (pillow.libs/libavif*.so; OAVIF_LIBAVIF overrides)"
+            else:
+                try:
+                    L = ctypes.CDLL(path)
+                    _bind(L)
+                    why = _check_layout(L)
+                except (OSError, AttributeError) as e:
+                    L, why = None, f"{path}: {e}"
+                if why is None:
+                    _state["lib"], _state["path"] = L, path
+                else:
+                    _state["why"] = why
+        if _state["lib"] is None:
+            raise AvifBridgeError("LibavifUnavailable", _state["why"])
+        return _state["lib"]
+
+
+def available() -> bool:
+    """True when a libavif whose struct layout passed the check is loaded (OAVIF_CODEC=pillow turns it off)."""
+    if os.environ.get("OAVIF_CODEC", "").strip().lower() == "pillow":
+        return False
+    try:
+        _lib()
+        return True
+    except AvifBridgeError:
+        return False
+
+
+def why_unavailable() -> Optional[str]:
+    if os.environ.get("OAVIF_CODEC", "").strip().lower() == "pillow":
+        return "OAVIF_CODEC=pillow"
+    try:
+        _lib()
+        return None
+    except AvifBridgeError as e:
+        return str(e)
+
+
+def versions() -> str:
+    L = _lib()
+    buf = ctypes.create_string_buffer(256)
+    L.avifCodecVersions(buf)
+    return f"libavif {L.avifVersion().decode()} ({buf.value.decode()})"
+
+
+def _fail(L, name: str, rc: int):
+    raise AvifBridgeError(name, L.avifResultToString(rc).decode())
+
+
+_depth_ok = {}
+
+
+def supports_depth(depth: int) -> bool:
+    """Whether the loaded library's AV1 encoder accepts `depth`-bit input (tried once, on a 16x16 frame).
+    libaom can be built without CONFIG_AV1_HIGHBITDEPTH -- the copy Pillow bundles is: aom_codec_enc_init
+    then fails with "Codec does not implement requested capability" and no 10-bit AVIF can be written,
+    whatever the binding.  dav1d decodes 10-bit either way."""
+    if depth not in _depth_ok:
+        class _O:   # AvifEncOptions' defaults that copyToEncoder reads, at the fastest speed
+            quality_alpha, speed, max_threads, tile_rows_log2, tile_cols_log2, auto_tiling = 0, 10, 1, 0, 0, True
+            tune, color_primaries, transfer_characteristics, matrix_coefficients = "ssim", 2, 2, 2
+        frame = np.full((16, 16, 3), 128 if depth == 8 else 512, np.uint8 if depth == 8 else np.uint16)
+        try:
+            encode(frame, depth, _O, 50)
+            _depth_ok[depth] = True
+        except AvifBridgeError:
+            _depth_ok[depth] = False
+    return _depth_ok[depth]
+
+
+def output_depth(tenbit: bool, hbd: bool) -> int:
+    """io.zig:546: `if (o.tenbit) 10 else if (e.src.hbd) 10 else 8`."""
+    return 10 if (tenbit or hbd) else 8
+
+
+def prescale_source(pixels: np.ndarray, out_depth: int) -> np.ndarray:
+    """The source rescaled to the encoder's depth (io.zig:566-617), ONCE per image instead of on every pass
+    (the loops are oavif_prescale_* of the C ABI, include/oavif_tq.h).  `pixels` is
+    (h, w, ch) uint8, or uint16 in the full 16-bit range for an hbd source."""
+    from . import tq
+    return tq.prescale(pixels, out_depth)
+
+
+def encode(scaled: np.ndarray, out_depth: int, o, q: int, icc: Optional[bytes] = None) -> bytes:
+    """io.encodeAvifToBuffer (io.zig:544-636).  `scaled` = prescale_source(pixels, out_depth): (h, w, 3|4),
+    uint8 for an 8-bit encode, uint16 holding 10-bit values for a 10-bit one.  `o` carries the fields of
+    AvifEncOptions that copyToEncoder reads (parse_args.zig:65-74) plus the CICP triple."""
+    L = _lib()
+    if scaled.ndim != 3 or scaled.shape[2] not in (3, 4):
+        # the reference hands 1- and 2-channel sources to libavif as if they were RGB (io.zig:564, a row-stride
+        # bug); callers here expand gray to RGB(A) first
+        raise AvifBridgeError("ConvertFailed", f"source has {scaled.shape[2] if scaled.ndim == 3 else '?'} channels")
+    if (out_depth == 8) != (scaled.dtype == np.uint8) or out_depth not in (8, 10):
+        raise AvifBridgeError("ConvertFailed", f"depth {out_depth} with {scaled.dtype} samples")
+    scaled = np.ascontiguousarray(scaled)
+    h, w, ch = scaled.shape
+    image = L.avifImageCreate(w, h, out_depth, _PIXEL_FORMAT_YUV444)
+    if not image:
+        raise AvifBridgeError("OutOfMemory")
+    enc = None
+    out = _RWData(None, 0)
+    try:
+        ctypes.c_uint16.from_address(image + _IMG_CP).value = int(o.color_primaries)
+        ctypes.c_uint16.from_address(image + _IMG_TC).value = int(o.transfer_characteristics)
+        ctypes.c_uint16.from_address(image + _IMG_MC).value = int(o.matrix_coefficients)
+        if icc:
+            if L.avifImageSetProfileICC(image, icc, len(icc)) != _RESULT_OK:
+                raise AvifBridgeError("SetICCProfileFailed")
+        rgb = ctypes.create_string_buffer(_RGB_SIZE)
+        L.avifRGBImageSetDefaults(rgb, image)
+        struct.pack_into("<I", rgb, _RGB_FORMAT, _RGB_FORMAT_RGBA if ch == 4 else _RGB_FORMAT_RGB)
+        struct.pack_into("<Q", rgb, _RGB_PIXELS, scaled.ctypes.data)
+        struct.pack_into("<I", rgb, _RGB_ROWBYTES, w * ch * scaled.itemsize)
+        struct.pack_into("<I", rgb, _RGB_DEPTH, out_depth)
+        rc = L.avifImageRGBToYUV(image, rgb)
+        if rc != _RESULT_OK:
+            _fail(L, "ConvertFailed", rc)
+        enc = L.avifEncoderCreate()
+        if not enc:
+            raise AvifBridgeError("OutOfMemory")
+        # copyToEncoder (parse_args.zig:65-74), then quality / qualityAlpha (io.zig:625-626)
+        ctypes.c_int32.from_address(enc + _ENC_SPEED).value = int(o.speed)
+        ctypes.c_int32.from_address(enc + _ENC_MAXTHREADS).value = int(o.max_threads)
+        ctypes.c_int32.from_address(enc + _ENC_TILEROWS).value = int(o.tile_rows_log2)
+        ctypes.c_int32.from_address(enc + _ENC_TILECOLS).value = int(o.tile_cols_log2)
+        ctypes.c_int32.from_address(enc + _ENC_AUTOTILING).value = 1 if o.auto_tiling else 0
+        rc = L.avifEncoderSetCodecSpecificOption(enc, b"tune", str(o.tune).encode())
+        if rc != _RESULT_OK:
+            _fail(L, "InvalidCodecOption", rc)
+        ctypes.c_int32.from_address(enc + _ENC_QUALITY).value = int(q)
+        ctypes.c_int32.from_address(enc + _ENC_QUALITYALPHA).value = int(o.quality_alpha)
+        rc = L.avifEncoderAddImage(enc, image, 1, _ADD_IMAGE_FLAG_SINGLE)
+        if rc != _RESULT_OK:
+            _fail(L, "AddImageFailed", rc)
+        rc = L.avifEncoderFinish(enc, ctypes.byref(out))
+        if rc != _RESULT_OK:
+            _fail(L, "FinishFailed", rc)
+        return ctypes.string_at(out.data, out.size)
+    finally:
+        if out.data:
+            L.avifRWDataFree(ctypes.byref(out))
+        if enc:
+            L.avifEncoderDestroy(enc)
+        L.avifImageDestroy(image)
+
+
+class DecodedFrame:
+    """What decodeAvifCommon leaves behind (io.zig:446-482): the decoder and libavif's own 8-bit RGB(A) rows.
+    `rows` is a (h, rowBytes) uint8 view of libavif's buffer, valid until close(); `channels` 3 or 4.  The
+    decoded-frame hand-off of the C ABI (`ssimu2_score_against_reference_strided`) takes exactly this."""
+
+    def __init__(self, L, dec, rgb, w, h, channels, depth, has_alpha):
+        self._L, self._dec, self._rgb = L, dec, rgb
+        self.width, self.height, self.channels, self.depth, self.has_alpha = w, h, channels, depth, has_alpha
+        pix, row = struct.unpack_from("<QI", rgb.raw, _RGB_PIXELS)
+        self.row_bytes = row
+        self.rows = np.ctypeslib.as_array((ctypes.c_uint8 * (row * h)).from_address(pix)).reshape(h, row)
+
+    def tight_rgb8(self) -> np.ndarray:
+        """io.decodeAvifToRgb's copy loop (io.zig:654-663): tight RGB8, alpha dropped."""
+        a = self.rows[:, : self.width * self.channels].reshape(self.height, self.width, self.channels)
+        return np.array(a[..., :3], order="C", copy=True)   # a copy: `rows` dies with close()
+
+    def close(self) -> None:
+        if self._rgb is not None:
+            self.rows = None
+            self._L.avifRGBImageFreePixels(self._rgb)
+            self._L.avifDecoderDestroy(self._dec)
+            self._rgb = self._dec = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def decode_common(data: bytes) -> DecodedFrame:
+    """decodeAvifCommon(avif_data, use_8bit = true) (io.zig:452-482)."""
+    L = _lib()
+    dec = L.avifDecoderCreate()
+    if not dec:
+        raise AvifBridgeError("OutOfMemory")
+    try:
+        if L.avifDecoderSetIOMemory(dec, data, len(data)) != _RESULT_OK:
+            raise AvifBridgeError("SetIOFailed")
+        rc = L.avifDecoderParse(dec)
+        if rc != _RESULT_OK:
+            _fail(L, "ParseFailed", rc)
+        rc = L.avifDecoderNextImage(dec)
+        if rc != _RESULT_OK:
+            _fail(L, "DecodeImageFailed", rc)
+        img = _ptr(dec, _DEC_IMAGE)
+        if not img:
+            raise AvifBridgeError("DecodeImageFailed", "decoder->image is null")
+        w, h, depth = _u32(img, _IMG_WIDTH), _u32(img, _IMG_HEIGHT), _u32(img, _IMG_DEPTH)
+        if not (0 < w <= 65536 and 0 < h <= 65536 and depth in (8, 10, 12)):
+            raise AvifBridgeError("DecodeImageFailed", f"implausible image header {w}x{h}, {depth}-bit")
+        has_alpha = _ptr(img, _IMG_ALPHAPLANE) != 0
+        rgb = ctypes.create_string_buffer(_RGB_SIZE)
+        L.avifRGBImageSetDefaults(rgb, img)
+        struct.pack_into("<I", rgb, _RGB_DEPTH, 8)                                   # io.zig:470-471
+        struct.pack_into("<I", rgb, _RGB_FORMAT, _RGB_FORMAT_RGBA if has_alpha else _RGB_FORMAT_RGB)
+        if L.avifRGBImageAllocatePixels(rgb) != _RESULT_OK:
+            raise AvifBridgeError("AllocatePixelsFailed")
+        rc = L.avifImageYUVToRGB(img, rgb)
+        if rc != _RESULT_OK:
+            L.avifRGBImageFreePixels(rgb)
+            _fail(L, "ConvertToRGBFailed", rc)
+    except BaseException:
+        L.avifDecoderDestroy(dec)
+        raise
+    return DecodedFrame(L, dec, rgb, w, h, 4 if has_alpha else 3, depth, has_alpha)
+
+
+def decode_rgb8(data: bytes) -> np.ndarray:
+    """io.decodeAvifToRgb (io.zig:638-666): (h, w, 3) uint8, whatever the depth of the bitstream."""
+    with decode_common(data) as f:
+        return f.tight_rgb8()
+
+
+def probe(data: bytes) -> dict:
+    """Geometry of an AVIF as libavif reports it after decoding its first image (tests, the CLI's notes)."""
+    with decode_common(data) as f:
+        return {"width": f.width, "height": f.height, "depth": f.depth, "alpha": f.has_alpha}

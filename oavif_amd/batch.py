@@ -4,7 +4,7 @@ measure.py runs the `oavif` binary once per image, one after another (measure.py
 Here every rank of a `torch.distributed` job (one process per GPU) takes its share of the same
 sorted list (measure.py:137-140) -- dealt largest file first to the least loaded rank, so the
 ranks' byte loads are even ("sort/largest-first if sizes vary") -- runs the
-target-quality search for each (CPU libavif/aom encode + dav1d decode through Pillow, scorer on
+target-quality search for each (CPU libavif/aom encode + dav1d decode through oavif_amd.avif_bridge, scorer on
 this rank's GPU) on host cores near that GPU (the rank pins itself to its slice of the node's
 cores before its first GPU call, oavif_amd.hostinfo), and the per-image result records are
 gathered to every rank with ONE all_gather (RCCL when the backend is nccl).  There is no
@@ -111,19 +111,31 @@ def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float 
         o = cli.AvifEncOptions()   # the reference's defaults (parse_args.zig:48-63): 1 thread, auto tiling
         o.speed, o.score_tgt, o.tolerance, o.max_pass = speed, score_tgt, tolerance, max_pass
     src = cli.load_source(str(path))
+    prepared = cli.encoder_input(src.pixels, o) if cli._bridge_on() else None   # hoisted out of the pass loop
     cache = {}
 
     def codec(q: int):
-        data = cli._encode(src.pixels, o, q, icc=src.icc)
+        data = cli._encode(src.pixels, o, q, icc=src.icc, prepared=prepared)
         cache.clear()
         cache[q] = data                      # EncBuffer holds only the last probe (tq.zig:31-35)
         return cli._decode_rgb(data), len(data)
 
-    r = tq.search_hip(scorer, src.rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
-                      max_pass=o.max_pass)
+    if cli._bridge_on():
+        from . import avif_bridge
+
+        def codec_frame(q: int):             # the decoded frame stays in libavif's buffer
+            data = cli._encode(src.pixels, o, q, icc=src.icc, prepared=prepared)
+            cache.clear()
+            cache[q] = data
+            return avif_bridge.decode_common(data), len(data)
+        r = tq.search_hip_frames(scorer, src.rgb, codec_frame, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                                 max_pass=o.max_pass)
+    else:
+        r = tq.search_hip(scorer, src.rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                          max_pass=o.max_pass)
     data = cache.get(r.q) if r.buf_q == r.q else None
     if data is None:                         # main.zig:109-113: re-encode at the chosen q
-        data = cli._encode(src.pixels, o, r.q, icc=src.icc)
+        data = cli._encode(src.pixels, o, r.q, icc=src.icc, prepared=prepared)
     if out_path is not None:
         out_path.write_bytes(data)
     return r.q, r.score, r.num_pass, len(data)
@@ -279,7 +291,7 @@ def run_batch(image_files: Sequence[Path], encode_fn: Callable[[int, Path], tupl
     rank (default: deal_largest_first over the files' sizes).
 
     `workers` > 1 runs that many images of the shard concurrently in threads: the CPU codec
-    (libavif/aom through Pillow releases the GIL) is 3-4 orders of magnitude slower than the GPU
+    (libavif/aom, called with the GIL released) is 3-4 orders of magnitude slower than the GPU
     score, so one image at a time leaves both the host cores and the GPU idle.  `encode_fn` must
     then be thread-safe (one scorer context per thread: contexts are not re-entrant)."""
     errors = {}
@@ -479,8 +491,11 @@ def main(argv=None) -> int:
         print(f"Host cores per rank{'' if pinned else ' (' + pin_note + ')'}: " + "; ".join(
             f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
         print(f"Worker threads per rank: {args.workers}; ranks per GPU: {ppg}; dealing: largest file first")
-        print("Note: the stand-in codec (Pillow's libavif) writes 8-bit AVIF where oavif defaults to 10-bit "
-              "(parse_args.zig:56): byte sizes and chosen quantizers are not those of the reference's measure.py run")
+        from . import cli
+        depth, note = cli.codec_depth(cli.AvifEncOptions().tenbit, False)   # the batch runs the reference's defaults
+        if note:
+            print("Note: oavif defaults to 10-bit AVIF (parse_args.zig:56) and this host's libaom writes 8-bit only: "
+                  "byte sizes and chosen quantizers are not those of the reference's measure.py run")
         print(f"\nResults written to {args.output_csv}")
     for sc in all_scorers:
         sc.close()

@@ -10,10 +10,16 @@ disagrees with it: --quality-alpha default 0 / max 99, --s
 
 What runs where: argument parsing and the search control are this repo's (the search is
 oavif_amd.tq over the C ABI); the SSIMULACRA2 score of every pass runs on the GPU; the AVIF
-encode / decode stay on the CPU in libavif (aom / dav1d) -- here through Pillow's bundled
-libavif, because the build image has no libavif headers.  Pillow's binding is 8-bit only, so
-`--tenbit 1` (the default) is accepted and reported, but the bitstream it writes is 8-bit;
-the scorer input is 8-bit RGB either way (io.zig:470-471).
+encode / decode stay on the CPU in libavif (aom / dav1d), called through oavif_amd.avif_bridge
+with the reference's own sequence of libavif calls and arguments (io.zig:544-666: YUV444, CICP,
+ICC, qualityAlpha, `tune`, tiling; decode forced to 8-bit RGB).  The library is the libavif
+1.4.1 that Pillow bundles (the image has no libavif headers or development package).  Its libaom
+is built WITHOUT high-bit-depth support, so no 10-bit AVIF can be written on this image:
+`--tenbit 1` (the default) is accepted and reported, the bitstream is 8-bit, and the run says
+so; with an aom that has it (OAVIF_LIBAVIF=/path/to/libavif.so) the same code writes 10-bit.
+The scorer input is 8-bit RGB either way (io.zig:470-471).  OAVIF_CODEC=pillow (or a libavif
+whose struct layout fails the bridge's check) falls back to Pillow's plugin: 8-bit, no
+`tune=iq`, no CICP.
 """
 from __future__ import annotations
 
@@ -227,12 +233,22 @@ options:
     eprint("\n\n\x1b[37mInput image formats: PNG, PAM, JPEG, WebP, or AVIF\x1b[0m")
 
 
+def _bridge_on() -> bool:
+    from . import avif_bridge
+    return avif_bridge.available()
+
+
 def print_version() -> None:
-    from PIL import features
     import oavif_amd
+    from . import avif_bridge
     eprint(f"oavif {VERSION}")
     eprint(f"scorer {oavif_amd.version()}")
-    eprint(f"libavif {features.version('avif')} (via Pillow)")
+    if avif_bridge.available():
+        eprint(f"{avif_bridge.versions()} (C API through oavif_amd.avif_bridge; 10-bit encode: "
+               f"{'yes' if avif_bridge.supports_depth(10) else 'no, aom built without high bit depth'})")
+    else:
+        from PIL import features
+        eprint(f"libavif {features.version('avif')} (via Pillow's plugin: {avif_bridge.why_unavailable()})")
 
 
 # ---- image I/O (CPU; counterpart of io.zig) -------------------------------------------------------
@@ -269,7 +285,9 @@ def load_source(path: str) -> Source:
             arr, _ch, hbd, icc = load_png(open(path, "rb").read())
         except PngError as e:
             raise CliError(e.name)
-        if hbd:   # the stand-in encoder is 8-bit: hand it what Image.toRGB8 makes of 16 bits (>> 8)
+        if hbd and codec_depth(True, True)[0] != 10:
+            # an encoder that cannot write 10-bit gets what Image.toRGB8 makes of 16 bits (>> 8, io.zig:602);
+            # one that can keeps the u16 samples and encodes `>> 6` (io.zig:587)
             arr = (arr >> 8).astype(np.uint8)
     else:
         im = Image.open(path)
@@ -288,6 +306,8 @@ def load_source(path: str) -> Source:
         rgb = np.repeat(arr[..., :1], 3, axis=2)
     else:
         rgb = arr[..., :3]
+    if rgb.dtype == np.uint16:   # Image.toRGB8: 16-bit -> >> 8 truncation (io.zig:63-95)
+        rgb = (rgb >> 8).astype(np.uint8)
     return Source(np.ascontiguousarray(rgb), arr, ch, hbd, icc)
 
 
@@ -305,12 +325,55 @@ _src_icc = None
 _USE_CLI_ICC = object()
 
 
-def _encode(src, o: AvifEncOptions, q: int, icc=_USE_CLI_ICC) -> bytes:
-    """io.encodeAvifToBuffer (io.zig:544-636) through Pillow: YUV444, the options of copyToEncoder."""
-    import io as _io
-    from PIL import Image
+def codec_depth(tenbit: bool, hbd: bool):
+    """-> (depth the encoder will write, note or None).  The reference writes 10-bit when --tenbit 1 or the
+    source is 16-bit (io.zig:546); here that needs a libaom with high-bit-depth support behind the bridge."""
+    from . import avif_bridge
+    want = avif_bridge.output_depth(tenbit, hbd)
+    if want == 8:
+        return 8, None
+    if not avif_bridge.available():
+        return 8, ("note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); the "
+                   f"libavif bridge is off ({avif_bridge.why_unavailable()}) and Pillow's plugin writes 8-bit, so "
+                   "sizes and the chosen q are not comparable with oavif's own output")
+    if not avif_bridge.supports_depth(10):
+        return 8, ("note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); this "
+                   "image's libaom has no high-bit-depth support (aom_codec_enc_init: \"Codec does not implement "
+                   "requested capability\"), so the bitstream is 8-bit and sizes / the chosen q are not comparable "
+                   "with oavif's own output; --tenbit 0 runs are the reference's calls exactly")
+    return 10, None
+
+
+def encoder_input(pixels, o: AvifEncOptions):
+    """The source as avifImageRGBToYUV gets it, computed ONCE per image instead of on every pass (io.zig:566-617
+    recomputes it per pass; SURVEY.md 8f rank 4, the loops are oavif_prescale_* of the C ABI).  -> (scaled
+    (h, w, 3|4) u8 or u16-holding-10-bit, depth).  Gray sources are expanded to RGB(A): the reference hands
+    them to libavif as if they were RGB (io.zig:564), a row-stride bug this mirror does not reproduce."""
+    import numpy as np
+    from . import avif_bridge
+    hbd = pixels.dtype == np.uint16
+    depth, _note = codec_depth(o.tenbit, hbd)
+    ch = pixels.shape[2]
+    if ch == 1:
+        pixels = np.repeat(pixels, 3, axis=2)
+    elif ch == 2:
+        pixels = np.concatenate([np.repeat(pixels[..., :1], 3, axis=2), pixels[..., 1:]], axis=2)
+    return avif_bridge.prescale_source(np.ascontiguousarray(pixels), depth), depth
+
+
+def _encode(src, o: AvifEncOptions, q: int, icc=_USE_CLI_ICC, prepared=None) -> bytes:
+    """io.encodeAvifToBuffer (io.zig:544-636).  `prepared` = encoder_input(src, o), hoisted by the callers that
+    encode one source many times."""
+    from . import avif_bridge
     if icc is _USE_CLI_ICC:
         icc = _src_icc
+    if avif_bridge.available():
+        scaled, depth = prepared if prepared is not None else encoder_input(src, o)
+        return avif_bridge.encode(scaled, depth, o, q, icc)
+    import io as _io
+    from PIL import Image
+    if src.dtype != "uint8":
+        src = (src >> 8).astype("uint8")
     mode = {1: "L", 2: "LA", 3: "RGB", 4: "RGBA"}[src.shape[2]]
     im = Image.fromarray(src[..., 0] if src.shape[2] == 1 else src, mode)
     buf = _io.BytesIO()
@@ -322,8 +385,12 @@ def _encode(src, o: AvifEncOptions, q: int, icc=_USE_CLI_ICC) -> bytes:
 
 
 def _decode_rgb(data: bytes):
+    """io.decodeAvifToRgb: 8-bit, alpha dropped (io.zig:638-666)."""
+    from . import avif_bridge
+    if avif_bridge.available():
+        return avif_bridge.decode_rgb8(data)
     from . import synth
-    return synth.avif_decode(data)  # io.decodeAvifToRgb: 8-bit, alpha dropped (io.zig:638-666)
+    return synth.avif_decode(data)
 
 
 # ---- driver (main.zig:37-117) -----------------------------------------------------------------------
@@ -363,16 +430,14 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         h, w, _ = rgb.shape
         eprint(f"Read {w}x{h}, {'RGBA' if channels > 3 else 'RGB'}, {16 if hbd else 8}-bit, "
                f"{os.path.getsize(inp)} bytes")
-        # The reference encodes 10-bit when --tenbit 1 or the source is 16-bit (io.zig:546-548).
-        # Pillow's libavif plugin, the stand-in codec here, writes 8-bit only: say what is written.
-        out_depth = 8
-        # ... after the reference's own lines, so their order (main.zig:78-116, what tools parse) is kept
-        depth_note = ("note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); "
-                      "the stand-in codec (Pillow's libavif) writes 8-bit, so sizes and the chosen q are not "
-                      "comparable with oavif's own output") if (o.tenbit or hbd) else None
+        # The reference encodes 10-bit when --tenbit 1 or the source is 16-bit (io.zig:546-548): say what
+        # IS written (the note goes after the reference's own lines, so that their order -- main.zig:78-116,
+        # what tools parse -- is kept)
+        out_depth, depth_note = codec_depth(o.tenbit, hbd)
+        prepared = encoder_input(src, o) if _bridge_on() else None   # once per image, not once per pass
         if o.quality is not None:  # bypass the search (main.zig:93-100)
             eprint(f"Encoding [q{o.quality}, speed {o.speed}, {out_depth}-bit]")
-            data = _encode(src, o, o.quality)
+            data = _encode(src, o, o.quality, prepared=prepared)
             open(out, "wb").write(data)
             eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
             if depth_note:
@@ -388,7 +453,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         cache = {}
 
         def codec(q: int):
-            data = _encode(src, o, q)
+            data = _encode(src, o, q, prepared=prepared)
             cache.clear()
             cache[q] = data  # EncBuffer keeps only the last probe (tq.zig:31-35)
             return _decode_rgb(data), len(data)
@@ -403,7 +468,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
             ctxs = [scorer] + [Ssimu2(dev, blur=blur_from_env()) for _ in range(min(fan, 16) - 1)]
 
             def codec_keep(q: int):
-                data = _encode(src, o, q)
+                data = _encode(src, o, q, prepared=prepared)
                 cache[q] = data  # every probe of a wave is kept: any of them may be the answer
                 return _decode_rgb(data), len(data)
             try:
@@ -414,13 +479,25 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
                 for c in ctxs[1:]:
                     c.close()
             r.buf_q = r.q if r.q in cache else r.buf_q
+        elif _bridge_on():
+            # decoded-frame hand-off: libavif's own RGB(A) rows go to the device as they
+            # are; the alpha-dropping copy loop of io.decodeAvifToRgb (io.zig:654-663) does not run on the host
+            from . import avif_bridge
+
+            def codec_frame(q: int):
+                data = _encode(src, o, q, prepared=prepared)
+                cache.clear()
+                cache[q] = data
+                return avif_bridge.decode_common(data), len(data)
+            r = tq.search_hip_frames(scorer, rgb, codec_frame, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                                     max_pass=o.max_pass)
         else:
             r = tq.search_hip(scorer, rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
                               max_pass=o.max_pass)
         eprint(f"Found q{r.q} (score {r.score:.2f}, {r.num_pass} passes)")
         data = cache.get(r.q) if r.buf_q == r.q else None
         if data is None:  # main.zig:109-113
-            data = _encode(src, o, r.q)
+            data = _encode(src, o, r.q, prepared=prepared)
         open(out, "wb").write(data)
         eprint(f"Compressed to {len(data)} bytes ({len(data) * 8 / (w * h):.3f} bpp)")
         if depth_note:

@@ -201,6 +201,34 @@ def search_hip(scorer: Ssimu2, ref_rgb: np.ndarray,
     return out
 
 
+def search_hip_frames(scorer: Ssimu2, ref_rgb: np.ndarray, codec_frame, score_tgt: float = 80.0,
+                      tolerance: float = 2.0, max_pass: int = 6) -> TQResult:
+    """The search with the decoded-frame hand-off: codec_frame(q) -> (frame, avif size)
+    where `frame` is what decodeAvifCommon leaves behind (oavif_amd.avif_bridge.DecodedFrame: libavif's own
+    8-bit RGB or RGBA rows, `rows` / `row_bytes` / `channels`, closed here after the score).  The rows go to
+    the device as they are (`ssimu2_score_against_reference_strided`); the alpha-dropping copy loop of
+    io.decodeAvifToRgb (io.zig:654-663) never runs on the host.  Same control flow, q and scores as
+    search_hip (the device unpacks to the same tight RGB8)."""
+    ref = np.ascontiguousarray(ref_rgb, dtype=np.uint8)
+    scorer.set_reference(ref)
+    last = {"size": 0}
+
+    def probe(q: int) -> float:
+        frame, size = codec_frame(int(q))
+        try:
+            if (frame.height, frame.width) != ref.shape[:2]:
+                raise ValueError(f"codec returned {frame.width}x{frame.height}, expected {ref.shape[1]}x{ref.shape[0]}")
+            score = scorer.score_decoded_against_reference(frame.rows.reshape(-1), frame.row_bytes, frame.channels)
+        finally:
+            frame.close()
+        last["size"] = int(size)
+        return score
+
+    out = find_target_quality(probe, score_tgt, tolerance, max_pass)
+    out.last_avif_size = last["size"]
+    return out
+
+
 def prescale(src: np.ndarray, out_depth: int) -> np.ndarray:
     """The source rescaled to the encoder's depth as io.encodeAvifToBuffer does on every pass
     (io.zig:566-617), to be computed once per search (include/oavif_tq.h).  src uint8 or uint16

@@ -336,6 +336,16 @@ def test_batch_and_cli_share_one_encode_path_and_keep_alpha(tmp_path, monkeypatc
         assert dec.shape == (48, 64, 3)                 # decodeAvifToRgb drops alpha (io.zig:654-663)
         return SimpleNamespace(q=61, score=80.5, num_pass=1, buf_q=61)
     monkeypatch.setattr(tq, "search_hip", fake_search)
+
+    def fake_search_frames(scorer, ref, codec_frame, score_tgt, tolerance, max_pass):
+        # with the libavif bridge on, the frame stays in libavif's RGBA rows
+        assert ref.shape == (48, 64, 3)
+        frame, _size = codec_frame(61)
+        assert (frame.width, frame.height, frame.channels) == (64, 48, 4)
+        assert frame.tight_rgb8().shape == (48, 64, 3)
+        frame.close()
+        return SimpleNamespace(q=61, score=80.5, num_pass=1, buf_q=61)
+    monkeypatch.setattr(tq, "search_hip_frames", fake_search_frames)
     out = tmp_path / "x.avif"
     q, score, passes, nbytes = batch.encode_image(None, src, out)
     assert (q, passes, nbytes) == (61, 1, out.stat().st_size)
