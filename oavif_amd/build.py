@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip.so")              # the product: C ABI of include/ssimu2_hip.h, oavif_tq.h
 INSTR_LIB_PATH = os.path.join(LIB_DIR, "liboavif_hip_instr.so")  # + include/ssimu2_hip_internal.h (bench / tests only)
+HOST_PATH = os.path.join(LIB_DIR, "oavif_host")   # csrc/oavif_host.c: main.zig's flow in C over the two public headers + libavif
 SOURCES = ["ssimu2_hip.hip", "tq.cpp", "png_ingest.cpp"]
 INSTR_SOURCES = ["ssimu2_instrument.hip", "tq.cpp", "png_ingest.cpp"]  # ssimu2_instrument.hip includes ssimu2_hip.hip
 
@@ -26,14 +27,30 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 library)")
 
 
-def needs_build() -> bool:
+def _newer_than(t: float, paths) -> bool:
+    return any(os.path.getmtime(d) > t for d in paths)
+
+
+def _headers():
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    return [os.path.join(inc, s) for s in os.listdir(inc)]
+
+
+def libs_need_build() -> bool:
     if not os.path.exists(LIB_PATH) or not os.path.exists(INSTR_LIB_PATH):
         return True
     t = min(os.path.getmtime(LIB_PATH), os.path.getmtime(INSTR_LIB_PATH))
-    deps = [os.path.join(CSRC, s) for s in os.listdir(CSRC)]
-    inc = os.path.join(os.path.dirname(_HERE), "include")
-    deps += [os.path.join(inc, s) for s in os.listdir(inc)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _newer_than(t, [os.path.join(CSRC, s) for s in os.listdir(CSRC) if s != "oavif_host.c"] + _headers())
+
+
+def host_needs_build() -> bool:
+    if not os.path.exists(HOST_PATH):
+        return True
+    return _newer_than(os.path.getmtime(HOST_PATH), [os.path.join(CSRC, "oavif_host.c"), LIB_PATH] + _headers())
+
+
+def needs_build() -> bool:
+    return libs_need_build() or host_needs_build()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -47,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
             return LIB_PATH
-        for target, sources in ((LIB_PATH, SOURCES), (INSTR_LIB_PATH, INSTR_SOURCES)):
+        for target, sources in ((LIB_PATH, SOURCES), (INSTR_LIB_PATH, INSTR_SOURCES)) if force or libs_need_build() else ():
             tmp = target + f".tmp{os.getpid()}"
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                    "-ffp-contract=off",  # arithmetic contract: every FMA is an explicit fmaf()
@@ -65,7 +82,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
             finally:
                 if os.path.exists(tmp):
                     os.unlink(tmp)
+        build_host(verbose)
     return LIB_PATH
+
+
+def build_host(verbose: bool = False) -> str:
+    """The C host (plain C over include/*.h; libavif is opened with dlopen at run time).  Linked against the
+    product library next to it ($ORIGIN), the HIP runtime resolved through the library's own dependencies."""
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    tmp = HOST_PATH + f".tmp{os.getpid()}"
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", inc,
+           os.path.join(CSRC, "oavif_host.c"), "-o", tmp, "-L", LIB_DIR, "-loavif_hip", "-ldl", "-lm",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, HOST_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return HOST_PATH
 
 
 if __name__ == "__main__":

@@ -1,0 +1,587 @@
+/*
+ * oavif_host.c -- the drop-in, end to end, as a compiled host: what oavif's main.zig does
+ * around the boundary (/root/reference/src/main.zig:37-117), in C over the two public headers.
+ *
+ *     oavif_host [options] <in.png|in.pam> <out.avif>
+ *
+ * The reference's host language is Zig and the image has no Zig toolchain, so the binding a
+ * maintainer adds (oavif_amd/zig/fssimu2.zig) cannot be compiled here.
+ * This file is the same host side in the language that CAN be compiled here, with nothing of
+ * Python in the loop:
+ *
+ *   main.zig:73-91    load the image, build the scorer's RGB8 reference (Image.toRGB8)
+ *   main.zig:93-100   -q: encode once
+ *   main.zig:102-116  findTargetQuality -> oavif_tq_find_target_quality (include/oavif_tq.h), whose
+ *                     pass (tq.zig:21-38) is the callback below: io.encodeAvifToBuffer and
+ *                     decodeAvifCommon against libavif's C API, call for call (io.zig:452-482,
+ *                     544-636), then the score of tq.zig:37 on the GPU through
+ *                     ssimu2_score_against_reference_strided (libavif's RGB(A) rows as they are:
+ *                     the copy loop of io.zig:654-663 never runs)
+ *   io.zig:566-617    the source is rescaled to the encoder's depth ONCE (oavif_prescale_*), not
+ *                     once per pass
+ *
+ * libavif: the image has a libavif 1.4.1 shared library (inside Pillow's wheel) and no header.
+ * The leading members of the four public structs used here are declared below from the public
+ * API of libavif 1.x, the library is opened with dlopen (OAVIF_LIBAVIF names it), and the
+ * documented defaults of avifEncoderCreate / avifDecoderCreate / avifImageCreate /
+ * avifRGBImageSetDefaults are read back through these declarations before anything is encoded:
+ * a library with another layout is refused.  PNG input goes through oavif_png_decode (the C ABI's
+ * loader with io.loadPNG's output rules), PAM through the reader below (io.zig:309-406).
+ *
+ * stderr carries the reference's lines in the reference's formats (main.zig:78-84,95,98,102,106,116:
+ * scripts/measure.py parses "N passes").  Exit code 0, or 1 with "error: <ZigErrorName>".
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <errno.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include "oavif_tq.h"
+#include "ssimu2_hip.h"
+
+#define VERSION "oavif_amd-0.1 (C host)"
+
+/* ---- libavif 1.x: the members this host touches (public API; checked at run time) --------------------- */
+typedef struct { uint8_t* data; size_t size; } avifRWData;
+typedef struct {
+    uint32_t width, height, depth;
+    int yuvFormat, yuvRange, yuvChromaSamplePosition;
+    uint8_t* yuvPlanes[3];
+    uint32_t yuvRowBytes[3];
+    int imageOwnsYUVPlanes;
+    uint8_t* alphaPlane;
+    uint32_t alphaRowBytes;
+    int imageOwnsAlphaPlane, alphaPremultiplied;
+    avifRWData icc;
+    uint16_t colorPrimaries, transferCharacteristics, matrixCoefficients;
+} avifImageHead; /* avifImage continues (clli, transforms, exif, xmp, ...): never touched */
+typedef struct {
+    uint32_t width, height, depth;
+    int format, chromaUpsampling, chromaDownsampling, avoidLibYUV, ignoreAlpha, alphaPremultiplied, isFloat;
+    int maxThreads;
+    uint8_t* pixels;
+    uint32_t rowBytes;
+} avifRGBImage;
+typedef struct {
+    int codecChoice, maxThreads, speed, keyframeInterval;
+    uint64_t timescale;
+    int repetitionCount;
+    uint32_t extraLayerCount;
+    int quality, qualityAlpha, minQuantizer, maxQuantizer, minQuantizerAlpha, maxQuantizerAlpha;
+    int tileRowsLog2, tileColsLog2, autoTiling;
+    int scalingMode[4];
+} avifEncoderHead; /* avifEncoder continues (ioStats, diag, data, ...) */
+typedef struct {
+    int codecChoice, maxThreads, requestedSource, allowProgressive, allowIncremental, ignoreExif, ignoreXMP;
+    uint32_t imageSizeLimit, imageDimensionLimit, imageCountLimit, strictFlags;
+    avifImageHead* image;
+} avifDecoderHead; /* avifDecoder continues */
+_Static_assert(offsetof(avifImageHead, alphaPlane) == 64 && offsetof(avifImageHead, icc) == 88 &&
+               offsetof(avifImageHead, colorPrimaries) == 104, "avifImage head");
+_Static_assert(offsetof(avifRGBImage, pixels) == 48 && offsetof(avifRGBImage, rowBytes) == 56, "avifRGBImage");
+_Static_assert(offsetof(avifEncoderHead, quality) == 32 && offsetof(avifEncoderHead, autoTiling) == 64, "avifEncoder head");
+_Static_assert(offsetof(avifDecoderHead, image) == 48, "avifDecoder head");
+enum { AVIF_OK = 0, AVIF_YUV444 = 1, AVIF_RGB = 0, AVIF_RGBA = 1, AVIF_ADD_IMAGE_FLAG_SINGLE = 2 };
+
+static struct {
+    const char* (*Version)(void);
+    const char* (*ResultToString)(int);
+    avifImageHead* (*ImageCreate)(uint32_t, uint32_t, uint32_t, int);
+    void (*ImageDestroy)(avifImageHead*);
+    int (*ImageSetProfileICC)(avifImageHead*, const uint8_t*, size_t);
+    void (*RGBImageSetDefaults)(avifRGBImage*, const avifImageHead*);
+    int (*RGBImageAllocatePixels)(avifRGBImage*);
+    void (*RGBImageFreePixels)(avifRGBImage*);
+    int (*ImageRGBToYUV)(avifImageHead*, const avifRGBImage*);
+    int (*ImageYUVToRGB)(const avifImageHead*, avifRGBImage*);
+    avifEncoderHead* (*EncoderCreate)(void);
+    void (*EncoderDestroy)(avifEncoderHead*);
+    int (*EncoderSetCodecSpecificOption)(avifEncoderHead*, const char*, const char*);
+    int (*EncoderAddImage)(avifEncoderHead*, const avifImageHead*, uint64_t, uint32_t);
+    int (*EncoderFinish)(avifEncoderHead*, avifRWData*);
+    void (*RWDataFree)(avifRWData*);
+    avifDecoderHead* (*DecoderCreate)(void);
+    void (*DecoderDestroy)(avifDecoderHead*);
+    int (*DecoderSetIOMemory)(avifDecoderHead*, const uint8_t*, size_t);
+    int (*DecoderParse)(avifDecoderHead*);
+    int (*DecoderNextImage)(avifDecoderHead*);
+} av;
+
+static const char* g_err = NULL; /* the reference's Zig error name of the failure */
+static char g_detail[320];
+static int fail(const char* name, const char* detail) {
+    g_err = name;
+    snprintf(g_detail, sizeof g_detail, "%s", detail ? detail : "");
+    return -1;
+}
+
+static int load_libavif(void) {
+    const char* path = getenv("OAVIF_LIBAVIF");
+    void* h = dlopen(path && *path ? path : "libavif.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libavif.so.16", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail("LibavifUnavailable", dlerror());
+#define SYM(field, name)                                                    \
+    do {                                                                    \
+        *(void**)(&av.field) = dlsym(h, name);                              \
+        if (!av.field) return fail("LibavifUnavailable", "missing " name);  \
+    } while (0)
+    SYM(Version, "avifVersion"); SYM(ResultToString, "avifResultToString");
+    SYM(ImageCreate, "avifImageCreate"); SYM(ImageDestroy, "avifImageDestroy");
+    SYM(ImageSetProfileICC, "avifImageSetProfileICC"); SYM(RGBImageSetDefaults, "avifRGBImageSetDefaults");
+    SYM(RGBImageAllocatePixels, "avifRGBImageAllocatePixels"); SYM(RGBImageFreePixels, "avifRGBImageFreePixels");
+    SYM(ImageRGBToYUV, "avifImageRGBToYUV"); SYM(ImageYUVToRGB, "avifImageYUVToRGB");
+    SYM(EncoderCreate, "avifEncoderCreate"); SYM(EncoderDestroy, "avifEncoderDestroy");
+    SYM(EncoderSetCodecSpecificOption, "avifEncoderSetCodecSpecificOption");
+    SYM(EncoderAddImage, "avifEncoderAddImage"); SYM(EncoderFinish, "avifEncoderFinish");
+    SYM(RWDataFree, "avifRWDataFree"); SYM(DecoderCreate, "avifDecoderCreate");
+    SYM(DecoderDestroy, "avifDecoderDestroy"); SYM(DecoderSetIOMemory, "avifDecoderSetIOMemory");
+    SYM(DecoderParse, "avifDecoderParse"); SYM(DecoderNextImage, "avifDecoderNextImage");
+#undef SYM
+    /* layout guard: the documented defaults, read back through the declarations above */
+    if (strncmp(av.Version(), "1.", 2) != 0) return fail("LibavifUnavailable", "not libavif 1.x");
+    avifEncoderHead* e = av.EncoderCreate();
+    if (!e) return fail("OutOfMemory", NULL);
+    const int enc_ok = e->codecChoice == 0 && e->maxThreads == 1 && e->speed == -1 && e->keyframeInterval == 0 &&
+                       e->timescale == 1 && e->repetitionCount == -1 && e->extraLayerCount == 0 &&
+                       e->minQuantizer == 0 && e->maxQuantizer == 63 && e->minQuantizerAlpha == 0 &&
+                       e->maxQuantizerAlpha == 63 && e->tileRowsLog2 == 0 && e->tileColsLog2 == 0 &&
+                       e->autoTiling == 0 && e->scalingMode[0] == 1 && e->scalingMode[1] == 1 &&
+                       e->scalingMode[2] == 1 && e->scalingMode[3] == 1;
+    av.EncoderDestroy(e);
+    avifDecoderHead* d = av.DecoderCreate();
+    if (!d) return fail("OutOfMemory", NULL);
+    const int dec_ok = d->maxThreads == 1 && d->imageSizeLimit == 16384u * 16384u && d->imageDimensionLimit == 32768 &&
+                       d->imageCountLimit == 12 * 3600 * 60 && d->image == NULL;
+    av.DecoderDestroy(d);
+    avifImageHead* im = av.ImageCreate(24, 16, 10, AVIF_YUV444);
+    if (!im) return fail("OutOfMemory", NULL);
+    avifRGBImage rgb;
+    memset(&rgb, 0xaa, sizeof rgb);
+    av.RGBImageSetDefaults(&rgb, im);
+    const int img_ok = im->width == 24 && im->height == 16 && im->depth == 10 && im->yuvFormat == AVIF_YUV444 &&
+                       im->yuvRange == 1 && im->alphaPlane == NULL && im->icc.data == NULL && im->icc.size == 0 &&
+                       im->colorPrimaries == 2 && im->transferCharacteristics == 2 && im->matrixCoefficients == 2;
+    const int rgb_ok = rgb.width == 24 && rgb.height == 16 && rgb.depth == 10 && rgb.format == AVIF_RGBA &&
+                       rgb.maxThreads == 1 && rgb.pixels == NULL && rgb.rowBytes == 0;
+    av.ImageDestroy(im);
+    if (!(enc_ok && dec_ok && img_ok && rgb_ok))
+        return fail("LibavifUnavailable", "struct layout of the loaded libavif differs from the 1.x one declared here");
+    return 0;
+}
+
+/* ---- options (parse_args.zig:48-63 defaults, :76-122 flags and ranges) ----------------------------------- */
+typedef struct {
+    int quality_alpha, speed, max_threads, tile_rows_log2, tile_cols_log2, auto_tiling;
+    double score_tgt;
+    int tenbit;
+    const char* tune;
+    double tolerance;
+    int max_pass, quality /* -1 = search */, color_primaries, transfer_characteristics, matrix_coefficients;
+} Options;
+
+static int int_arg(int* i, int argc, char** argv, long lo, long hi, const char* name, int* out) {
+    if (*i >= argc || argv[*i][0] == '-') { /* parse_args.zig:126: a value starting with '-' counts as missing */
+        fprintf(stderr, "Error: Missing %s value\n", name);
+        return fail("MissingOptionValue", NULL);
+    }
+    char* end;
+    errno = 0;
+    const long v = strtol(argv[*i], &end, 10);
+    if (*end || errno) return fail("InvalidCharacter", NULL);
+    if (v < lo || v > hi) {
+        fprintf(stderr, "Error: %s must be between %ld and %ld\n", name, lo, hi);
+        return fail("InvalidOptionValue", NULL);
+    }
+    ++*i;
+    *out = (int)v;
+    return 0;
+}
+static int float_arg(int* i, int argc, char** argv, double lo, double hi, const char* name, double* out) {
+    if (*i >= argc || argv[*i][0] == '-') {
+        fprintf(stderr, "Error: Missing %s value\n", name);
+        return fail("MissingOptionValue", NULL);
+    }
+    char* end;
+    const double v = strtod(argv[*i], &end);
+    if (*end || end == argv[*i]) return fail("InvalidCharacter", NULL);
+    if (v < lo || v > hi) {
+        fprintf(stderr, "Error: %s must be between %g and %g\n", name, lo, hi);
+        return fail("InvalidOptionValue", NULL);
+    }
+    ++*i;
+    *out = v;
+    return 0;
+}
+static int bool_arg(int* i, int argc, char** argv, const char* name, int* out) {
+    if (*i >= argc || argv[*i][0] == '-') {
+        fprintf(stderr, "Error: Missing %s value\n", name);
+        return fail("MissingOptionValue", NULL);
+    }
+    if (strcmp(argv[*i], "0") != 0 && strcmp(argv[*i], "1") != 0) {
+        fprintf(stderr, "Error: %s must be 0 or 1\n", name);
+        return fail("InvalidOptionValue", NULL);
+    }
+    *out = argv[(*i)++][0] == '1';
+    return 0;
+}
+
+static int parse_args(Options* o, int argc, char** argv, const char** in, const char** out) {
+    for (int i = 1; i < argc;) {
+        const char* a = argv[i++];
+#define IS(s) (strcmp(a, s) == 0)
+        int rc = 0;
+        if (IS("-s") || IS("--speed")) rc = int_arg(&i, argc, argv, 0, 10, "--speed", &o->speed);
+        else if (IS("-t") || IS("--score-tgt")) rc = float_arg(&i, argc, argv, 30, 100, "--score-tgt", &o->score_tgt);
+        else if (IS("--quality-alpha")) rc = int_arg(&i, argc, argv, 0, 99, "--quality-alpha", &o->quality_alpha);
+        else if (IS("--max-threads")) rc = int_arg(&i, argc, argv, 1, 255, "--max-threads", &o->max_threads);
+        else if (IS("--tile-rows-log2")) rc = int_arg(&i, argc, argv, 0, 6, "--tile-rows-log2", &o->tile_rows_log2);
+        else if (IS("--tile-cols-log2")) rc = int_arg(&i, argc, argv, 0, 6, "--tile-cols-log2", &o->tile_cols_log2);
+        else if (IS("--auto-tiling")) rc = bool_arg(&i, argc, argv, "--auto-tiling", &o->auto_tiling);
+        else if (IS("--tune")) {
+            if (i >= argc || argv[i][0] == '-') { fprintf(stderr, "Error: Missing --tune value\n"); return fail("MissingOptionValue", NULL); }
+            const char* t = argv[i++];
+            if (strcmp(t, "ssim") && strcmp(t, "iq") && strcmp(t, "ssimulacra2")) {
+                fprintf(stderr, "Error: --tune must be one of: ssim, iq, ssimulacra2\n");
+                return fail("InvalidTuneMode", NULL);
+            }
+            o->tune = t;
+        } else if (IS("--tenbit")) rc = bool_arg(&i, argc, argv, "--tenbit", &o->tenbit);
+        else if (IS("--tolerance")) rc = float_arg(&i, argc, argv, 1, 100, "--tolerance", &o->tolerance);
+        else if (IS("--max-pass")) rc = int_arg(&i, argc, argv, 1, 12, "--max-pass", &o->max_pass);
+        else if (IS("-q") || IS("--quality")) rc = int_arg(&i, argc, argv, 0, 100, "--quality", &o->quality);
+        else if (IS("--color-primaries")) rc = int_arg(&i, argc, argv, 1, 22, "--color-primaries", &o->color_primaries);
+        else if (IS("--transfer-characteristics")) rc = int_arg(&i, argc, argv, 1, 18, "--transfer-characteristics", &o->transfer_characteristics);
+        else if (IS("--matrix-coefficients")) rc = int_arg(&i, argc, argv, 0, 14, "--matrix-coefficients", &o->matrix_coefficients);
+        else if (!*in) *in = a;
+        else if (!*out) *out = a;
+        else { fprintf(stderr, "Error: Unexpected argument: %s\n", a); return fail("UnexpectedArgument", NULL); }
+#undef IS
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ---- image load: io.zig's Image (io.zig:42-55) ------------------------------------------------------------ */
+typedef struct {
+    uint32_t w, h, channels; /* 3 or 4 after load (gray is expanded: see load_pam) */
+    int hbd;                 /* data is u16, full 16-bit range */
+    uint8_t* data;
+    uint8_t* icc;
+    size_t icc_len;
+} Image;
+
+static uint8_t* read_file(const char* path, size_t* len) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { fail("FileNotFound", path); return NULL; }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t* b = (uint8_t*)malloc(n > 0 ? (size_t)n : 1);
+    if (!b || fread(b, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(b); fail("ReadFailed", path); return NULL; }
+    fclose(f);
+    *len = (size_t)n;
+    return b;
+}
+
+/* io.loadPAM (io.zig:309-406): P7, WIDTH / HEIGHT / DEPTH / MAXVAL 255 / TUPLTYPE, ENDHDR */
+static int load_pam(const uint8_t* b, size_t n, Image* im) {
+    if (n < 3 || memcmp(b, "P7\n", 3) != 0) return fail("InvalidPAMHeader", NULL);
+    size_t p = 3;
+    long w = 0, h = 0, depth = 0, maxval = 0;
+    int ended = 0;
+    while (p < n && !ended) {
+        size_t e = p;
+        while (e < n && b[e] != '\n') ++e;
+        char line[128];
+        const size_t L = e - p < sizeof line - 1 ? e - p : sizeof line - 1;
+        memcpy(line, b + p, L);
+        line[L] = 0;
+        p = e + 1;
+        if (!strcmp(line, "ENDHDR") || !*line) ended = 1;
+        else if (!strncmp(line, "WIDTH ", 6)) w = atol(line + 6);
+        else if (!strncmp(line, "HEIGHT ", 7)) h = atol(line + 7);
+        else if (!strncmp(line, "DEPTH ", 6)) depth = atol(line + 6);
+        else if (!strncmp(line, "MAXVAL ", 7)) maxval = atol(line + 7);
+    }
+    if (!ended || w <= 0 || h <= 0 || depth < 1 || depth > 4) return fail("InvalidPAMHeader", NULL);
+    if (maxval != 255) return fail("UnsupportedMaxval", NULL);
+    const size_t px = (size_t)w * (size_t)h;
+    if (n - p < px * (size_t)depth) return fail("UnexpectedEndOfFile", NULL);
+    /* gray (+alpha) is expanded to RGB(A): the reference hands 1- and 2-channel data to libavif as if it
+       were RGB (io.zig:564), a row-stride bug this host does not reproduce */
+    const uint32_t ch = depth <= 2 ? (uint32_t)depth + 2 : (uint32_t)depth;
+    uint8_t* d = (uint8_t*)malloc(px * ch);
+    if (!d) return fail("OutOfMemory", NULL);
+    const uint8_t* s = b + p;
+    for (size_t i = 0; i < px; ++i)
+        for (uint32_t c = 0; c < ch; ++c)
+            d[i * ch + c] = depth >= 3 ? s[i * depth + c] : (c < 3 ? s[i * depth] : s[i * depth + 1]);
+    im->w = (uint32_t)w; im->h = (uint32_t)h; im->channels = ch; im->hbd = 0; im->data = d;
+    return 0;
+}
+
+static int load_png(const uint8_t* b, size_t n, Image* im) { /* io.loadPNG (io.zig:242-307) via the C ABI */
+    oavif_png_info info;
+    int rc = oavif_png_info_from_memory(b, n, &info);
+    if (rc) return fail(rc == OAVIF_PNG_ERR_HEADER ? "GetHeaderFailed" : rc == OAVIF_PNG_ERR_SIZE ? "ImageSizeFailed" : "DecodeFailed", NULL);
+    uint8_t* d = (uint8_t*)malloc(info.data_bytes ? info.data_bytes : 1);
+    uint8_t* icc = info.icc_bytes ? (uint8_t*)malloc(info.icc_bytes) : NULL;
+    if (!d || (info.icc_bytes && !icc)) { free(d); free(icc); return fail("OutOfMemory", NULL); }
+    rc = oavif_png_decode(b, n, d, info.data_bytes, icc, info.icc_bytes);
+    if (rc) { free(d); free(icc); return fail("DecodeFailed", NULL); }
+    im->w = info.width; im->h = info.height; im->channels = info.channels; im->hbd = info.hbd;
+    im->data = d; im->icc = icc; im->icc_len = info.icc_bytes;
+    return 0;
+}
+
+static int load_image(const char* path, Image* im) {
+    const char* dot = strrchr(path, '.');
+    size_t n = 0;
+    if (!dot || (strcasecmp(dot, ".png") && strcasecmp(dot, ".pam"))) return fail("UnsupportedImageFormat", "this host reads PNG and PAM");
+    uint8_t* b = read_file(path, &n);
+    if (!b) return -1;
+    const int rc = strcasecmp(dot, ".png") == 0 ? load_png(b, n, im) : load_pam(b, n, im);
+    free(b);
+    return rc;
+}
+
+/* ---- the pass: io.encodeAvifToBuffer + decodeAvifCommon + the score (tq.zig:21-38) ------------------------- */
+typedef struct {
+    const Options* o;
+    const Image* src;
+    const void* scaled; /* the source at the encoder's depth, computed once */
+    uint32_t out_depth;
+    ssimu2_ctx* scorer;
+    /* EncBuffer (main.zig:11-19): the AVIF bytes of the LAST probe */
+    uint8_t* buf;
+    size_t buf_size;
+    int buf_q;
+    double encode_ms, decode_ms, score_ms;
+} EncCtx;
+
+#include <time.h>
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_size) { /* io.zig:544-636 */
+    const Options* o = e->o;
+    const Image* s = e->src;
+    avifImageHead* image = av.ImageCreate(s->w, s->h, e->out_depth, AVIF_YUV444);
+    if (!image) return fail("OutOfMemory", NULL);
+    avifEncoderHead* enc = NULL;
+    avifRWData output = {NULL, 0};
+    int rc = -1, r;
+    image->colorPrimaries = (uint16_t)o->color_primaries;
+    image->transferCharacteristics = (uint16_t)o->transfer_characteristics;
+    image->matrixCoefficients = (uint16_t)o->matrix_coefficients;
+    if (s->icc && av.ImageSetProfileICC(image, s->icc, s->icc_len) != AVIF_OK) { fail("SetICCProfileFailed", NULL); goto done; }
+    avifRGBImage rgb;
+    memset(&rgb, 0, sizeof rgb);
+    av.RGBImageSetDefaults(&rgb, image);
+    rgb.format = s->channels == 4 ? AVIF_RGBA : AVIF_RGB;
+    rgb.pixels = (uint8_t*)(uintptr_t)e->scaled;
+    rgb.rowBytes = s->w * s->channels * (e->out_depth > 8 ? 2u : 1u);
+    rgb.depth = e->out_depth;
+    if ((r = av.ImageRGBToYUV(image, &rgb)) != AVIF_OK) { fail("ConvertFailed", av.ResultToString(r)); goto done; }
+    enc = av.EncoderCreate();
+    if (!enc) { fail("OutOfMemory", NULL); goto done; }
+    enc->qualityAlpha = o->quality_alpha; /* copyToEncoder (parse_args.zig:65-74) */
+    enc->speed = o->speed;
+    enc->maxThreads = o->max_threads;
+    enc->tileRowsLog2 = o->tile_rows_log2;
+    enc->tileColsLog2 = o->tile_cols_log2;
+    enc->autoTiling = o->auto_tiling;
+    if (av.EncoderSetCodecSpecificOption(enc, "tune", o->tune) != AVIF_OK) { fail("InvalidCodecOption", NULL); goto done; }
+    enc->quality = (int)q; /* io.zig:625-626 */
+    enc->qualityAlpha = o->quality_alpha;
+    if ((r = av.EncoderAddImage(enc, image, 1, AVIF_ADD_IMAGE_FLAG_SINGLE)) != AVIF_OK) { fail("AddImageFailed", av.ResultToString(r)); goto done; }
+    if ((r = av.EncoderFinish(enc, &output)) != AVIF_OK) { fail("FinishFailed", av.ResultToString(r)); goto done; }
+    *out = (uint8_t*)malloc(output.size);
+    if (!*out) { fail("OutOfMemory", NULL); goto done; }
+    memcpy(*out, output.data, output.size);
+    *out_size = output.size;
+    rc = 0;
+done:
+    if (output.data) av.RWDataFree(&output);
+    if (enc) av.EncoderDestroy(enc);
+    av.ImageDestroy(image);
+    return rc;
+}
+
+static int probe(void* user, uint32_t q, double* out_score) { /* computeScoreAtQuality (tq.zig:21-38) */
+    EncCtx* e = (EncCtx*)user;
+    uint8_t* avif = NULL;
+    size_t avif_size = 0;
+    double t0 = now_ms();
+    if (encode_to_buffer(e, q, &avif, &avif_size)) return -1;
+    double t1 = now_ms();
+    e->encode_ms += t1 - t0;
+    /* decodeAvifCommon(avif, use_8bit = true) (io.zig:452-482) */
+    int rc = -1, r;
+    avifDecoderHead* dec = av.DecoderCreate();
+    avifRGBImage rgb;
+    memset(&rgb, 0, sizeof rgb);
+    if (!dec) { fail("OutOfMemory", NULL); goto done; }
+    if (av.DecoderSetIOMemory(dec, avif, avif_size) != AVIF_OK) { fail("SetIOFailed", NULL); goto done; }
+    if ((r = av.DecoderParse(dec)) != AVIF_OK) { fail("ParseFailed", av.ResultToString(r)); goto done; }
+    if ((r = av.DecoderNextImage(dec)) != AVIF_OK) { fail("DecodeImageFailed", av.ResultToString(r)); goto done; }
+    const avifImageHead* img = dec->image;
+    if (!img || img->width != e->src->w || img->height != e->src->h) { fail("DecodeImageFailed", "unexpected frame size"); goto done; }
+    av.RGBImageSetDefaults(&rgb, img);
+    rgb.depth = 8;                                        /* io.zig:470-471 */
+    rgb.format = img->alphaPlane ? AVIF_RGBA : AVIF_RGB;  /* io.zig:473 */
+    if (av.RGBImageAllocatePixels(&rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
+    if ((r = av.ImageYUVToRGB(img, &rgb)) != AVIF_OK) { fail("ConvertToRGBFailed", av.ResultToString(r)); goto done; }
+    double t2 = now_ms();
+    e->decode_ms += t2 - t1;
+    /* tq.zig:31-35: the buffer of this probe replaces the previous one */
+    free(e->buf);
+    e->buf = avif; e->buf_size = avif_size; e->buf_q = (int)q;
+    avif = NULL;
+    /* tq.zig:37, without the copy loop of io.zig:654-663: libavif's rows as they are */
+    r = ssimu2_score_against_reference_strided(e->scorer, rgb.pixels, rgb.rowBytes, rgb.format == AVIF_RGBA ? 4 : 3, out_score);
+    e->score_ms += now_ms() - t2;
+    if (r != SSIMU2_OK) { fail("ScorerFailed", ssimu2_last_error(e->scorer)); goto done; }
+    rc = 0;
+done:
+    if (rgb.pixels) av.RGBImageFreePixels(&rgb);
+    if (dec) av.DecoderDestroy(dec);
+    free(avif);
+    return rc;
+}
+
+static int write_file(const char* path, const uint8_t* b, size_t n) {
+    FILE* f = fopen(path, "wb");
+    if (!f || fwrite(b, 1, n, f) != n) { if (f) fclose(f); return fail("WriteFailed", path); }
+    fclose(f);
+    return 0;
+}
+
+static int run(int argc, char** argv) {
+    Options o = {0, 9, 1, 0, 0, 1, 80.0, 1, "iq", 2.0, 6, -1, 2, 2, 2}; /* parse_args.zig:48-63 */
+    const char *in = NULL, *out = NULL;
+    if (parse_args(&o, argc, argv, &in, &out)) return -1;
+    if (!in || !out) return fail("MissingInputOrOutput", NULL);
+    const int device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
+    if (o.quality < 0) ssimu2_prefetch(device); /* the HIP start-up runs behind the image load and the first encode */
+    if (load_libavif()) return -1;
+    Image src;
+    memset(&src, 0, sizeof src);
+    if (load_image(in, &src)) return -1;
+    struct stat st;
+    stat(in, &st);
+    fprintf(stderr, "Read %ux%u, %s, %d-bit, %lld bytes\n", src.w, src.h, src.channels > 3 ? "RGBA" : "RGB",
+            src.hbd ? 16 : 8, (long long)st.st_size);
+    const size_t px = (size_t)src.w * src.h, nsamp = px * src.channels;
+    /* e.rgb: Image.toRGB8 (io.zig:57-133) unless the source already is RGB8 (main.zig:86) */
+    uint8_t* rgb8 = src.data;
+    if (src.channels != 3 || src.hbd) {
+        rgb8 = (uint8_t*)malloc(px * 3);
+        if (!rgb8) return fail("OutOfMemory", NULL);
+        for (size_t i = 0; i < px; ++i)
+            for (int c = 0; c < 3; ++c)
+                rgb8[i * 3 + c] = src.hbd ? (uint8_t)(((const uint16_t*)src.data)[i * src.channels + c] >> 8)
+                                          : src.data[i * src.channels + c];
+    }
+    /* io.zig:546; a libaom without high-bit-depth support (this image's) cannot write 10-bit: probed once */
+    uint32_t out_depth = (o.tenbit || src.hbd) ? 10 : 8;
+    const char* depth_note = NULL;
+    if (out_depth == 10) {
+        Options po = o;
+        po.speed = 10;
+        uint16_t tiny[16 * 16 * 3];
+        for (int i = 0; i < 16 * 16 * 3; ++i) tiny[i] = 512;
+        Image ti = {16, 16, 3, 0, (uint8_t*)tiny, NULL, 0};
+        EncCtx pe = {&po, &ti, tiny, 10, NULL, NULL, 0, -1, 0, 0, 0};
+        uint8_t* pb = NULL;
+        size_t pn = 0;
+        if (encode_to_buffer(&pe, 50, &pb, &pn)) {
+            out_depth = 8;
+            depth_note = "note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); this "
+                         "image's libaom has no high-bit-depth support, so the bitstream is 8-bit";
+        }
+        free(pb);
+        g_err = NULL;
+    }
+    /* io.zig:566-617, hoisted out of the pass loop */
+    void* scaled = src.data;
+    if (!src.hbd && out_depth == 10) {
+        scaled = malloc(nsamp * 2);
+        if (!scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_8_to_10(src.data, nsamp, (uint16_t*)scaled);
+    } else if (src.hbd && out_depth == 10) {
+        scaled = malloc(nsamp * 2);
+        if (!scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_16_to_10((const uint16_t*)src.data, nsamp, (uint16_t*)scaled);
+    } else if (src.hbd) {
+        scaled = malloc(nsamp);
+        if (!scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_16_to_8((const uint16_t*)src.data, nsamp, (uint8_t*)scaled);
+    }
+    EncCtx e = {&o, &src, scaled, out_depth, NULL, NULL, 0, -1, 0, 0, 0};
+    if (o.quality >= 0) { /* main.zig:93-100 */
+        fprintf(stderr, "Encoding [q%d, speed %d, %u-bit]\n", o.quality, o.speed, out_depth);
+        uint8_t* b = NULL;
+        size_t n = 0;
+        if (encode_to_buffer(&e, (uint32_t)o.quality, &b, &n) || write_file(out, b, n)) return -1;
+        fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", n, n * 8.0 / (double)px);
+        if (depth_note) fprintf(stderr, "%s\n", depth_note);
+        return 0;
+    }
+    if (o.score_tgt == floor(o.score_tgt)) /* Zig's {} on an f64 prints 80 for 80.0 */
+        fprintf(stderr, "Searching [tgt %.0f±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
+    else
+        fprintf(stderr, "Searching [tgt %g±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
+    int rc = ssimu2_ctx_create(device, NULL, &e.scorer);
+    if (rc != SSIMU2_OK) return fail(rc == SSIMU2_ERR_NO_DEVICE ? "NoDevice" : "ScorerFailed", ssimu2_last_error(NULL));
+    /* the blur of the search path: the published recursion unless OAVIF_SSIMU2_BLUR says otherwise (as the
+       Zig shim's `blur` and the Python mirror: INTEGRATION.md section 2e) */
+    const char* bm = getenv("OAVIF_SSIMU2_BLUR");
+    int mode = SSIMU2_BLUR_RECURSIVE;
+    if (bm && !strcmp(bm, "fir")) mode = SSIMU2_BLUR_FIR;
+    else if (bm && (!strcmp(bm, "recursive_fma") || !strcmp(bm, "iir_fma"))) mode = SSIMU2_BLUR_RECURSIVE_FMA;
+    if ((rc = ssimu2_ctx_set_blur(e.scorer, mode)) || (rc = ssimu2_set_reference(e.scorer, rgb8, src.w, src.h)))
+        return fail("ScorerFailed", ssimu2_last_error(e.scorer));
+    oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
+    oavif_tq_result res;
+    rc = oavif_tq_find_target_quality(&to, probe, &e, &res);
+    if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
+    fprintf(stderr, "Found q%u (score %.2f, %u passes)\n", res.q, res.score, res.num_pass);
+    if (e.buf_q == (int)res.q) { /* main.zig:109-113 */
+        if (write_file(out, e.buf, e.buf_size)) return -1;
+    } else {
+        free(e.buf);
+        e.buf = NULL;
+        if (encode_to_buffer(&e, res.q, &e.buf, &e.buf_size) || write_file(out, e.buf, e.buf_size)) return -1;
+    }
+    fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", e.buf_size, e.buf_size * 8.0 / (double)px);
+    if (depth_note) fprintf(stderr, "%s\n", depth_note);
+    if (getenv("OAVIF_HOST_TIMES")) /* not one of the reference's lines: only on request */
+        fprintf(stderr, "times: encode %.1f ms, decode %.1f ms, upload+score %.2f ms over %u passes\n", e.encode_ms,
+                e.decode_ms, e.score_ms, res.num_pass);
+    ssimu2_ctx_destroy(e.scorer);
+    free(e.buf);
+    if (scaled != src.data) free(scaled);
+    if (rgb8 != src.data) free(rgb8);
+    free(src.data);
+    free(src.icc);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    fprintf(stderr, "\x1b[31moavif\x1b[0m | %s\n", VERSION);
+    if (run(argc, argv)) {
+        fprintf(stderr, "error: %s%s%s\n", g_err ? g_err : "Unexpected", g_detail[0] ? ": " : "", g_detail);
+        return 1;
+    }
+    return 0;
+}

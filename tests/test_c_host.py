@@ -1,0 +1,124 @@
+"""oavif_amd/csrc/oavif_host.c: main.zig's flow (main.zig:37-117) as a compiled C program over the two public
+headers and libavif -- the drop-in end to end with no Python in the loop.
+
+CPU part: it builds, its `-q` bypass writes the bytes the Python mirror writes (both make the reference's libavif
+calls, io.zig:544-636), argument errors carry the reference's names, and without a GPU a search fails loudly.
+GPU part: a whole search (PNG / PAM in, AVIF out) prints the same "Found q.. (score .., N passes)" line and
+writes the same file as the Python mirror on the same scorer."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oavif_amd import avif_bridge as ab
+from oavif_amd import build as obuild
+from oavif_amd import cli, pam, synth
+
+pytestmark = pytest.mark.skipif(not ab.available(), reason=f"libavif bridge unavailable: {ab.why_unavailable()}")
+
+
+@pytest.fixture(scope="module")
+def host(hip_lib):
+    if obuild.host_needs_build():
+        obuild.build_host()
+    return obuild.HOST_PATH
+
+
+def _env(**kw):
+    e = dict(os.environ, OAVIF_LIBAVIF=ab._find_library())
+    e.update(kw)
+    return e
+
+
+def _run(host, args, **env):
+    return subprocess.run([host, *args], capture_output=True, text=True, timeout=300, env=_env(**env))
+
+
+def _inputs(tmp_path, w=200, h=136, seed=1):
+    from PIL import Image
+    ref = synth.make_ref(w, h, seed)
+    png = tmp_path / "a.png"
+    Image.fromarray(ref).save(png)
+    rgba = np.dstack([ref, np.tile(np.linspace(0, 255, w, dtype=np.uint8), (h, 1))])
+    p = tmp_path / "b.pam"
+    p.write_bytes(pam.write_pam(rgba))
+    return ref, png, p
+
+
+def test_bypass_writes_the_python_mirrors_bytes(host, tmp_path, capsys):
+    _ref, png, p = _inputs(tmp_path)
+    for args, src in ((["-q", "61", "--tenbit", "0"], png),
+                      (["-q", "40", "--tenbit", "0", "--quality-alpha", "90", "--tune", "ssim", "-s", "8"], p),
+                      (["--quality", "70", "--color-primaries", "1", "--transfer-characteristics", "13",
+                        "--matrix-coefficients", "6", "--tenbit", "0"], png)):
+        r = _run(host, [*args, str(src), str(tmp_path / "c.avif")])
+        assert r.returncode == 0, r.stderr
+        assert cli.main([*args, str(src), str(tmp_path / "p.avif")]) == 0
+        perr = capsys.readouterr().err.splitlines()
+        cerr = r.stderr.splitlines()
+        assert cerr[1:4] == perr[1:4]                       # Read / Encoding / Compressed lines (main.zig:78-98)
+        assert re.fullmatch(r"Read 200x136, RGBA?, 8-bit, \d+ bytes", cerr[1])
+        assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
+
+
+def test_default_depth_is_reported_like_the_mirror(host, tmp_path):
+    _ref, png, _p = _inputs(tmp_path)
+    r = _run(host, ["-q", "50", str(png), str(tmp_path / "c.avif")])     # --tenbit 1 is the default
+    assert r.returncode == 0
+    want = 10 if ab.supports_depth(10) else 8
+    assert f"Encoding [q50, speed 9, {want}-bit]" in r.stderr
+    assert ("note: the reference would write 10-bit" in r.stderr) == (want == 8)
+    assert ab.probe((tmp_path / "c.avif").read_bytes())["depth"] == want
+
+
+def test_argument_errors_carry_the_references_names(host, tmp_path):
+    _ref, png, _p = _inputs(tmp_path, 32, 32)
+    cases = [(["--speed", "11", str(png), "x.avif"], "InvalidOptionValue", "Error: --speed must be between 0 and 10"),
+             (["--tenbit", "2", str(png), "x.avif"], "InvalidOptionValue", "Error: --tenbit must be 0 or 1"),
+             (["--max-pass"], "MissingOptionValue", "Error: Missing --max-pass value"),
+             (["--tune", "psnr", str(png), "x.avif"], "InvalidTuneMode", ""),
+             ([str(png)], "MissingInputOrOutput", ""),
+             ([str(png), "x.avif", "extra"], "UnexpectedArgument", "Error: Unexpected argument: extra"),
+             (["-q", "50", str(tmp_path / "nope.png"), "x.avif"], "FileNotFound", ""),
+             (["-q", "50", "in.jpg", "x.avif"], "UnsupportedImageFormat", "")]
+    for args, name, line in cases:
+        r = _run(host, args)
+        assert r.returncode == 1 and f"error: {name}" in r.stderr, (args, r.stderr)
+        assert line in r.stderr
+    bad = tmp_path / "bad.pam"
+    bad.write_bytes(b"P7\nWIDTH 2\nHEIGHT 2\nDEPTH 3\nMAXVAL 65535\nTUPLTYPE RGB\nENDHDR\n" + bytes(24))
+    assert "error: UnsupportedMaxval" in _run(host, ["-q", "50", str(bad), "x.avif"]).stderr    # io.zig:368
+    r = _run(host, ["-q", "50", str(png), str(tmp_path / "x.avif")], OAVIF_LIBAVIF="/nonexistent/libavif.so")
+    assert r.returncode == 1 and "error: LibavifUnavailable" in r.stderr
+
+
+def test_search_without_a_gpu_fails_loudly(host, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _ref, png, _p = _inputs(tmp_path, 64, 48)
+    r = _run(host, [str(png), str(tmp_path / "x.avif")])
+    assert r.returncode == 1 and "error: NoDevice" in r.stderr and not (tmp_path / "x.avif").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blur", ["recursive", "fir"])
+def test_search_end_to_end_equals_the_python_mirror(host, tmp_path, capsys, monkeypatch, blur):
+    """The C host and the Python mirror drive the same search code (oavif_tq_find_target_quality), the same
+    libavif calls and the same scorer: same probes, same q, same score to the printed digits, same file."""
+    _ref, png, p = _inputs(tmp_path, 320, 240, seed=303)
+    monkeypatch.setenv("OAVIF_SSIMU2_BLUR", blur)
+    for args, src in ((["--score-tgt", "75", "--tolerance", "1.5", "--tenbit", "0"], png),
+                      (["-t", "88", "--tolerance", "1", "--max-pass", "8", "--tenbit", "0", "--quality-alpha", "80"], p)):
+        r = _run(host, [*args, str(src), str(tmp_path / "c.avif")], OAVIF_SSIMU2_BLUR=blur, OAVIF_HOST_TIMES="1")
+        assert r.returncode == 0, r.stderr
+        assert cli.main([*args, str(src), str(tmp_path / "p.avif")]) == 0
+        perr = capsys.readouterr().err.splitlines()
+        cerr = r.stderr.splitlines()
+        assert cerr[1:5] == perr[1:5], (cerr, perr)          # Read, Searching, Found, Compressed
+        m = re.fullmatch(r"Found q(\d+) \(score (-?\d+\.\d{2}), (\d+) passes\)", cerr[3])
+        assert m and re.search(r"(\d+)\s+passes?", cerr[3]).group(1) == m.group(3)      # measure.py:27
+        assert cerr[-1].startswith("times: encode ")
+        assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
