@@ -626,21 +626,50 @@ def main() -> int:
             handoff["ms_cpu_copy_loop_io_zig_654"] = round((time.perf_counter() - tt) / 3 * 1e3, 3)
         out["decoded_frame_handoff_4k"] = handoff
 
-        # ---- one REAL search pass end to end (tq.zig:21-38): CPU encode -> CPU decode -> upload
-        # -> GPU score, with Pillow's libavif (aom speed 9, YUV444) standing in for oavif's ----
+        # ---- one REAL search pass end to end (tq.zig:21-38): CPU encode -> CPU decode -> upload -> GPU
+        # score, through libavif's C API with the reference's own calls and defaults (oavif_amd.avif_bridge:
+        # YUV444, tune=iq, speed 9, ONE encoder thread, parse_args.zig:48-63); the decoded frame goes to the
+        # scorer in libavif's rows.  Pillow's plugin only if the bridge is unavailable ----
+        codec4k, codec_label = None, None
         if world == 1 and synth.have_avif() and not args.no_cpu_baseline:
             try:
-                t_e = time.perf_counter()
-                data = synth.avif_encode(ref, 65, speed=9)
-                t_d = time.perf_counter()
-                dec = synth.avif_decode(data)
-                t_s = time.perf_counter()
-                real_score = scorer.score_against_reference(dec)
-                t_x = time.perf_counter()
+                from oavif_amd import avif_bridge as _ab
+                from oavif_amd import cli as _cli
+                if _ab.available():
+                    _o = _cli.AvifEncOptions()
+                    _depth, _dnote = _cli.codec_depth(_o.tenbit, False)
+                    _scaled = _ab.prescale_source(ref, _depth)          # once per image
+                    codec_label = (f"{_ab.versions()} through oavif_amd.avif_bridge: the reference's calls and defaults "
+                                   f"(YUV444, tune={_o.tune}, speed {_o.speed}, {_o.max_threads} encoder thread), "
+                                   f"{_depth}-bit" + (" (the reference's default is 10-bit: this image's libaom has no "
+                                                      "high-bit-depth support)" if _dnote else ""))
+
+                    def codec4k(q):
+                        d_ = _ab.encode(_scaled, _depth, _o, q)
+                        return _ab.decode_rgb8(d_), len(d_)
+                    t_e = time.perf_counter()
+                    data = _ab.encode(_scaled, _depth, _o, 65)
+                    t_d = time.perf_counter()
+                    frame = _ab.decode_common(data)
+                    t_s = time.perf_counter()
+                    real_score = scorer.score_decoded_against_reference(frame.rows.reshape(-1), frame.row_bytes,
+                                                                        frame.channels)
+                    t_x = time.perf_counter()
+                    frame.close()
+                else:
+                    codec_label = f"Pillow's libavif plugin (bridge unavailable: {_ab.why_unavailable()}), 1 encoder thread"
+                    codec4k = lambda q: synth.avif_roundtrip(ref, q, speed=9, max_threads=1)
+                    t_e = time.perf_counter()
+                    data = synth.avif_encode(ref, 65, speed=9, max_threads=1)
+                    t_d = time.perf_counter()
+                    dec = synth.avif_decode(data)
+                    t_s = time.perf_counter()
+                    real_score = scorer.score_against_reference(dec)
+                    t_x = time.perf_counter()
                 out["search_pass_end_to_end_4k"] = {
                     "encode_ms": round((t_d - t_e) * 1e3, 1), "decode_ms": round((t_s - t_d) * 1e3, 1),
                     "upload_plus_score_ms": round((t_x - t_s) * 1e3, 3), "q": 65,
-                    "score": round(real_score, 4), "avif_bytes": len(data),
+                    "score": round(real_score, 4), "avif_bytes": len(data), "codec": codec_label,
                     "note": "the GPU share of a pass is the last term; libaom encode dominates"}
             except Exception as e:  # the codec is not part of the measured path
                 out["search_pass_end_to_end_4k"] = {"error": str(e)}
@@ -649,11 +678,10 @@ def main() -> int:
         # threads: same result, waves instead of passes of encode latency.
         # Encoder threads = 1 as oavif defaults (--max-threads, parse_args.zig:51), which is
         # what leaves host cores idle for speculative probes -------------------------------------
-        if world == 1 and synth.have_avif() and not args.no_cpu_baseline:
+        if world == 1 and codec4k is not None and not args.no_cpu_baseline:
             try:
                 from oavif_amd import tq as _tqs
                 fan = max(1, min(6, (usable_cores() or 2) - 2))
-                codec4k = lambda q: synth.avif_roundtrip(ref, q, speed=9, max_threads=1)
                 ctxs = [oavif_amd.Ssimu2(local_rank) for _ in range(fan)]
                 cases = []
                 try:
@@ -673,8 +701,8 @@ def main() -> int:
                     for c_ in ctxs:
                         c_.close()
                 out["search_end_to_end_4k"] = {
-                    "fanout": fan, "encoder_threads": 1, "cases": cases,
-                    "note": "Pillow libavif/aom speed 9 stands in for oavif's encoder; the first wave of the "
+                    "fanout": fan, "encoder_threads": 1, "cases": cases, "codec": codec_label,
+                    "note": "the first wave of the "
                             "speculative search is the model's guess alone (first_wave_fanout = 1), so a "
                             "search that ends on its first pass issues one probe like the sequential one; "
                             "speculation (and the reference upload to further contexts) starts with wave 2"}
