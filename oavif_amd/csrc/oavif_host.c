@@ -466,7 +466,25 @@ static int write_file(const char* path, const uint8_t* b, size_t n) {
     return 0;
 }
 
-static int run(int argc, char** argv) {
+typedef struct { /* everything run() allocates, released on every path */
+    Image src;
+    uint8_t* rgb8;
+    void* scaled;
+    EncCtx e;
+    uint8_t* once;
+} Run;
+
+static void run_free(Run* r) {
+    if (r->e.scorer) ssimu2_ctx_destroy(r->e.scorer);
+    free(r->e.buf);
+    free(r->once);
+    if (r->scaled != r->src.data) free(r->scaled);
+    if (r->rgb8 != r->src.data) free(r->rgb8);
+    free(r->src.data);
+    free(r->src.icc);
+}
+
+static int run_inner(Run* r, int argc, char** argv) {
     Options o = {0, 9, 1, 0, 0, 1, 80.0, 1, "iq", 2.0, 6, -1, 2, 2, 2}; /* parse_args.zig:48-63 */
     const char *in = NULL, *out = NULL;
     if (parse_args(&o, argc, argv, &in, &out)) return -1;
@@ -474,26 +492,26 @@ static int run(int argc, char** argv) {
     const int device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
     if (o.quality < 0) ssimu2_prefetch(device); /* the HIP start-up runs behind the image load and the first encode */
     if (load_libavif()) return -1;
-    Image src;
-    memset(&src, 0, sizeof src);
-    if (load_image(in, &src)) return -1;
+    Image* src = &r->src;
+    if (load_image(in, src)) return -1;
     struct stat st;
+    memset(&st, 0, sizeof st);
     stat(in, &st);
-    fprintf(stderr, "Read %ux%u, %s, %d-bit, %lld bytes\n", src.w, src.h, src.channels > 3 ? "RGBA" : "RGB",
-            src.hbd ? 16 : 8, (long long)st.st_size);
-    const size_t px = (size_t)src.w * src.h, nsamp = px * src.channels;
+    fprintf(stderr, "Read %ux%u, %s, %d-bit, %lld bytes\n", src->w, src->h, src->channels > 3 ? "RGBA" : "RGB",
+            src->hbd ? 16 : 8, (long long)st.st_size);
+    const size_t px = (size_t)src->w * src->h, nsamp = px * src->channels;
     /* e.rgb: Image.toRGB8 (io.zig:57-133) unless the source already is RGB8 (main.zig:86) */
-    uint8_t* rgb8 = src.data;
-    if (src.channels != 3 || src.hbd) {
-        rgb8 = (uint8_t*)malloc(px * 3);
-        if (!rgb8) return fail("OutOfMemory", NULL);
+    r->rgb8 = src->data;
+    if (src->channels != 3 || src->hbd) {
+        r->rgb8 = (uint8_t*)malloc(px * 3);
+        if (!r->rgb8) return fail("OutOfMemory", NULL);
         for (size_t i = 0; i < px; ++i)
             for (int c = 0; c < 3; ++c)
-                rgb8[i * 3 + c] = src.hbd ? (uint8_t)(((const uint16_t*)src.data)[i * src.channels + c] >> 8)
-                                          : src.data[i * src.channels + c];
+                r->rgb8[i * 3 + c] = src->hbd ? (uint8_t)(((const uint16_t*)src->data)[i * src->channels + c] >> 8)
+                                              : src->data[i * src->channels + c];
     }
     /* io.zig:546; a libaom without high-bit-depth support (this image's) cannot write 10-bit: probed once */
-    uint32_t out_depth = (o.tenbit || src.hbd) ? 10 : 8;
+    uint32_t out_depth = (o.tenbit || src->hbd) ? 10 : 8;
     const char* depth_note = NULL;
     if (out_depth == 10) {
         Options po = o;
@@ -511,28 +529,29 @@ static int run(int argc, char** argv) {
         }
         free(pb);
         g_err = NULL;
+        g_detail[0] = 0;
     }
     /* io.zig:566-617, hoisted out of the pass loop */
-    void* scaled = src.data;
-    if (!src.hbd && out_depth == 10) {
-        scaled = malloc(nsamp * 2);
-        if (!scaled) return fail("OutOfMemory", NULL);
-        oavif_prescale_8_to_10(src.data, nsamp, (uint16_t*)scaled);
-    } else if (src.hbd && out_depth == 10) {
-        scaled = malloc(nsamp * 2);
-        if (!scaled) return fail("OutOfMemory", NULL);
-        oavif_prescale_16_to_10((const uint16_t*)src.data, nsamp, (uint16_t*)scaled);
-    } else if (src.hbd) {
-        scaled = malloc(nsamp);
-        if (!scaled) return fail("OutOfMemory", NULL);
-        oavif_prescale_16_to_8((const uint16_t*)src.data, nsamp, (uint8_t*)scaled);
+    r->scaled = src->data;
+    if (!src->hbd && out_depth == 10) {
+        r->scaled = malloc(nsamp * 2);
+        if (!r->scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_8_to_10(src->data, nsamp, (uint16_t*)r->scaled);
+    } else if (src->hbd && out_depth == 10) {
+        r->scaled = malloc(nsamp * 2);
+        if (!r->scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_16_to_10((const uint16_t*)src->data, nsamp, (uint16_t*)r->scaled);
+    } else if (src->hbd) {
+        r->scaled = malloc(nsamp);
+        if (!r->scaled) return fail("OutOfMemory", NULL);
+        oavif_prescale_16_to_8((const uint16_t*)src->data, nsamp, (uint8_t*)r->scaled);
     }
-    EncCtx e = {&o, &src, scaled, out_depth, NULL, NULL, 0, -1, 0, 0, 0};
+    EncCtx* e = &r->e;
+    e->o = &o; e->src = src; e->scaled = r->scaled; e->out_depth = out_depth; e->buf_q = -1;
     if (o.quality >= 0) { /* main.zig:93-100 */
         fprintf(stderr, "Encoding [q%d, speed %d, %u-bit]\n", o.quality, o.speed, out_depth);
-        uint8_t* b = NULL;
         size_t n = 0;
-        if (encode_to_buffer(&e, (uint32_t)o.quality, &b, &n) || write_file(out, b, n)) return -1;
+        if (encode_to_buffer(e, (uint32_t)o.quality, &r->once, &n) || write_file(out, r->once, n)) return -1;
         fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", n, n * 8.0 / (double)px);
         if (depth_note) fprintf(stderr, "%s\n", depth_note);
         return 0;
@@ -541,7 +560,7 @@ static int run(int argc, char** argv) {
         fprintf(stderr, "Searching [tgt %.0f±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
     else
         fprintf(stderr, "Searching [tgt %g±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
-    int rc = ssimu2_ctx_create(device, NULL, &e.scorer);
+    int rc = ssimu2_ctx_create(device, NULL, &e->scorer);
     if (rc != SSIMU2_OK) return fail(rc == SSIMU2_ERR_NO_DEVICE ? "NoDevice" : "ScorerFailed", ssimu2_last_error(NULL));
     /* the blur of the search path: the published recursion unless OAVIF_SSIMU2_BLUR says otherwise (as the
        Zig shim's `blur` and the Python mirror: INTEGRATION.md section 2e) */
@@ -549,32 +568,34 @@ static int run(int argc, char** argv) {
     int mode = SSIMU2_BLUR_RECURSIVE;
     if (bm && !strcmp(bm, "fir")) mode = SSIMU2_BLUR_FIR;
     else if (bm && (!strcmp(bm, "recursive_fma") || !strcmp(bm, "iir_fma"))) mode = SSIMU2_BLUR_RECURSIVE_FMA;
-    if ((rc = ssimu2_ctx_set_blur(e.scorer, mode)) || (rc = ssimu2_set_reference(e.scorer, rgb8, src.w, src.h)))
-        return fail("ScorerFailed", ssimu2_last_error(e.scorer));
+    if ((rc = ssimu2_ctx_set_blur(e->scorer, mode)) || (rc = ssimu2_set_reference(e->scorer, r->rgb8, src->w, src->h)))
+        return fail("ScorerFailed", ssimu2_last_error(e->scorer));
     oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
     oavif_tq_result res;
-    rc = oavif_tq_find_target_quality(&to, probe, &e, &res);
+    rc = oavif_tq_find_target_quality(&to, probe, e, &res);
     if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
     fprintf(stderr, "Found q%u (score %.2f, %u passes)\n", res.q, res.score, res.num_pass);
-    if (e.buf_q == (int)res.q) { /* main.zig:109-113 */
-        if (write_file(out, e.buf, e.buf_size)) return -1;
+    if (e->buf_q == (int)res.q) { /* main.zig:109-113 */
+        if (write_file(out, e->buf, e->buf_size)) return -1;
     } else {
-        free(e.buf);
-        e.buf = NULL;
-        if (encode_to_buffer(&e, res.q, &e.buf, &e.buf_size) || write_file(out, e.buf, e.buf_size)) return -1;
+        free(e->buf);
+        e->buf = NULL;
+        if (encode_to_buffer(e, res.q, &e->buf, &e->buf_size) || write_file(out, e->buf, e->buf_size)) return -1;
     }
-    fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", e.buf_size, e.buf_size * 8.0 / (double)px);
+    fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", e->buf_size, e->buf_size * 8.0 / (double)px);
     if (depth_note) fprintf(stderr, "%s\n", depth_note);
     if (getenv("OAVIF_HOST_TIMES")) /* not one of the reference's lines: only on request */
-        fprintf(stderr, "times: encode %.1f ms, decode %.1f ms, upload+score %.2f ms over %u passes\n", e.encode_ms,
-                e.decode_ms, e.score_ms, res.num_pass);
-    ssimu2_ctx_destroy(e.scorer);
-    free(e.buf);
-    if (scaled != src.data) free(scaled);
-    if (rgb8 != src.data) free(rgb8);
-    free(src.data);
-    free(src.icc);
+        fprintf(stderr, "times: encode %.1f ms, decode %.1f ms, upload+score %.2f ms over %u passes\n", e->encode_ms,
+                e->decode_ms, e->score_ms, res.num_pass);
     return 0;
+}
+
+static int run(int argc, char** argv) {
+    Run r;
+    memset(&r, 0, sizeof r);
+    const int rc = run_inner(&r, argc, argv);
+    run_free(&r);
+    return rc;
 }
 
 int main(int argc, char** argv) {

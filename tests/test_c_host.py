@@ -122,3 +122,43 @@ def test_search_end_to_end_equals_the_python_mirror(host, tmp_path, capsys, monk
         assert m and re.search(r"(\d+)\s+passes?", cerr[3]).group(1) == m.group(3)      # measure.py:27
         assert cerr[-1].startswith("times: encode ")
         assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
+
+
+def test_host_is_clean_under_sanitizers(tmp_path, hip_lib):
+    """ASan + UBSan build of the host (CPU; libavif and the product library stay uninstrumented): the bypass on
+    PNG / RGBA PAM, every argument error, unreadable and corrupted inputs, and a search that stops at NoDevice --
+    no report, no leak on any path (LeakSanitizer on)."""
+    import shutil
+    import torch
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc missing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "oavif_amd", "lib")
+    exe = str(tmp_path / "host_san")
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=gnu11",
+                    "-I", os.path.join(root, "include"), os.path.join(root, "oavif_amd", "csrc", "oavif_host.c"),
+                    "-o", exe, "-L", libdir, "-loavif_hip", "-ldl", "-lm", f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath-link,/opt/rocm/lib"], check=True, capture_output=True)
+    _ref, png, p = _inputs(tmp_path, 96, 64)
+    raw = png.read_bytes()
+    (tmp_path / "cut.png").write_bytes(raw[: len(raw) // 2])
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x5A
+    (tmp_path / "flip.png").write_bytes(bytes(flipped))
+    praw = p.read_bytes()
+    (tmp_path / "cut.pam").write_bytes(praw[: len(praw) - 100])
+    (tmp_path / "hdr.pam").write_bytes(b"P7\nWIDTH 99999\nHEIGHT 99999\nDEPTH 4\nMAXVAL 255\nENDHDR\n" + bytes(64))
+    out = str(tmp_path / "o.avif")
+    cases = [(["-q", "60", "--tenbit", "0", str(png), out], 0), (["-q", "60", str(p), out], 0),
+             (["-q", "30", "--quality-alpha", "99", "--tune", "ssimulacra2", "--tenbit", "0", str(p), out], 0),
+             (["--speed", "99", str(png), out], 1), (["--max-pass"], 1), ([str(png)], 1),
+             (["-q", "5", str(tmp_path / "nope.png"), out], 1), (["-q", "5", str(tmp_path / "cut.png"), out], 1),
+             (["-q", "5", str(tmp_path / "flip.png"), out], 1), (["-q", "5", str(tmp_path / "cut.pam"), out], 1),
+             (["-q", "5", str(tmp_path / "hdr.pam"), out], 1)]
+    if not torch.cuda.is_available():
+        cases.append(([str(png), out], 1))          # the search path up to ssimu2_ctx_create
+    for args, want in cases:
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300,
+                           env=_env(ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stderr[-3000:])
+        assert r.returncode == want, (args, r.stderr[-800:])
