@@ -227,3 +227,27 @@ def test_search_with_decoded_frame_hand_off_equals_the_tight_copy_path(monkeypat
     assert all(f._rgb is None and f.rows is None for f in frames)          # every frame was closed after its score
     for (q, _s), a in zip(r.history, seen):
         assert np.array_equal(a, ab.decode_rgb8(ab.encode(rgba, 8, o, int(q))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha", [False, True])
+def test_hand_off_search_equals_tight_copy_search_on_the_device(scorer, alpha):
+    """tq.search_hip_frames (libavif's RGB / RGBA rows to ssimu2_score_against_reference_strided) against
+    tq.search_hip (io.decodeAvifToRgb's tight copy to ssimu2_score_against_reference): the same probes with
+    the same score bits, the same quantizer."""
+    from oavif_amd import tq
+    ref = synth.make_ref(333, 211, 21)          # rows of 999 / 1332 bytes: not multiples of anything
+    src = np.dstack([ref, np.tile(np.linspace(30, 255, 333, dtype=np.uint8), (211, 1))]) if alpha else ref
+    o = _opts(tenbit=False, quality_alpha=85)
+    data = {}
+
+    def enc(q):
+        if q not in data:
+            data[q] = ab.encode(src, 8, o, q)
+        return data[q]
+    for tgt in (70.0, 84.0, 93.0):
+        a = tq.search_hip(scorer, ref, lambda q: (ab.decode_rgb8(enc(q)), len(enc(q))), score_tgt=tgt, tolerance=1.0)
+        b = tq.search_hip_frames(scorer, ref, lambda q: (ab.decode_common(enc(q)), len(enc(q))), score_tgt=tgt,
+                                 tolerance=1.0)
+        assert (a.q, a.score, a.num_pass, a.buf_q, a.history) == (b.q, b.score, b.num_pass, b.buf_q, b.history)
+        assert a.last_avif_size == b.last_avif_size == len(enc(a.buf_q))
