@@ -276,67 +276,106 @@ def prescale_source(pixels: np.ndarray, out_depth: int) -> np.ndarray:
     return tq.prescale(pixels, out_depth)
 
 
-def encode(scaled: np.ndarray, out_depth: int, o, q: int, icc: Optional[bytes] = None) -> bytes:
-    """io.encodeAvifToBuffer (io.zig:544-636).  `scaled` = prescale_source(pixels, out_depth): (h, w, 3|4),
-    uint8 for an 8-bit encode, uint16 holding 10-bit values for a 10-bit one.  `o` carries the fields of
-    AvifEncOptions that copyToEncoder reads (parse_args.zig:65-74) plus the CICP triple."""
-    L = _lib()
-    if scaled.ndim != 3 or scaled.shape[2] not in (3, 4):
-        # the reference hands 1- and 2-channel sources to libavif as if they were RGB (io.zig:564, a row-stride
-        # bug); callers here expand gray to RGB(A) first
-        raise AvifBridgeError("ConvertFailed", f"source has {scaled.shape[2] if scaled.ndim == 3 else '?'} channels")
-    if (out_depth == 8) != (scaled.dtype == np.uint8) or out_depth not in (8, 10):
-        raise AvifBridgeError("ConvertFailed", f"depth {out_depth} with {scaled.dtype} samples")
-    scaled = np.ascontiguousarray(scaled)
-    h, w, ch = scaled.shape
-    image = L.avifImageCreate(w, h, out_depth, _PIXEL_FORMAT_YUV444)
-    if not image:
-        raise AvifBridgeError("OutOfMemory")
-    enc = None
-    out = _RWData(None, 0)
-    try:
-        ctypes.c_uint16.from_address(image + _IMG_CP).value = int(o.color_primaries)
-        ctypes.c_uint16.from_address(image + _IMG_TC).value = int(o.transfer_characteristics)
-        ctypes.c_uint16.from_address(image + _IMG_MC).value = int(o.matrix_coefficients)
-        if icc:
-            if L.avifImageSetProfileICC(image, icc, len(icc)) != _RESULT_OK:
-                raise AvifBridgeError("SetICCProfileFailed")
-        rgb = ctypes.create_string_buffer(_RGB_SIZE)
-        L.avifRGBImageSetDefaults(rgb, image)
-        struct.pack_into("<I", rgb, _RGB_FORMAT, _RGB_FORMAT_RGBA if ch == 4 else _RGB_FORMAT_RGB)
-        struct.pack_into("<Q", rgb, _RGB_PIXELS, scaled.ctypes.data)
-        struct.pack_into("<I", rgb, _RGB_ROWBYTES, w * ch * scaled.itemsize)
-        struct.pack_into("<I", rgb, _RGB_DEPTH, out_depth)
-        rc = L.avifImageRGBToYUV(image, rgb)
-        if rc != _RESULT_OK:
-            _fail(L, "ConvertFailed", rc)
+class EncoderSource:
+    """The source as the encoder takes it -- the avifImage of io.zig:550-623: created, tagged (CICP, ICC) and
+    converted from RGB(A) to YUV444 -- made ONCE per image.  io.encodeAvifToBuffer rebuilds it on every pass
+    (avifImageCreate + avifImageRGBToYUV over the whole frame: 15 % of a 4K encode at speed 9), although only
+    `quality` changes between the passes of a search (io.zig:625).  Same planes, same bitstream; the pre-scaling
+    hoist of SURVEY.md 8f rank 4 taken one step further.  encode() only reads the image, so the probes of a
+    speculative search may encode from one EncoderSource on several threads at once."""
+
+    def __init__(self, scaled: np.ndarray, out_depth: int, o, icc: Optional[bytes] = None):
+        L = self._L = _lib()
+        self._image = None
+        if scaled.ndim != 3 or scaled.shape[2] not in (3, 4):
+            # the reference hands 1- and 2-channel sources to libavif as if they were RGB (io.zig:564, a
+            # row-stride bug); callers here expand gray to RGB(A) first
+            raise AvifBridgeError("ConvertFailed", f"source has {scaled.shape[2] if scaled.ndim == 3 else '?'} channels")
+        if (out_depth == 8) != (scaled.dtype == np.uint8) or out_depth not in (8, 10):
+            raise AvifBridgeError("ConvertFailed", f"depth {out_depth} with {scaled.dtype} samples")
+        scaled = np.ascontiguousarray(scaled)
+        h, w, ch = scaled.shape
+        self.width, self.height, self.channels, self.depth = w, h, ch, out_depth
+        image = L.avifImageCreate(w, h, out_depth, _PIXEL_FORMAT_YUV444)
+        if not image:
+            raise AvifBridgeError("OutOfMemory")
+        try:
+            ctypes.c_uint16.from_address(image + _IMG_CP).value = int(o.color_primaries)
+            ctypes.c_uint16.from_address(image + _IMG_TC).value = int(o.transfer_characteristics)
+            ctypes.c_uint16.from_address(image + _IMG_MC).value = int(o.matrix_coefficients)
+            if icc:
+                if L.avifImageSetProfileICC(image, icc, len(icc)) != _RESULT_OK:
+                    raise AvifBridgeError("SetICCProfileFailed")
+            rgb = ctypes.create_string_buffer(_RGB_SIZE)
+            L.avifRGBImageSetDefaults(rgb, image)
+            struct.pack_into("<I", rgb, _RGB_FORMAT, _RGB_FORMAT_RGBA if ch == 4 else _RGB_FORMAT_RGB)
+            struct.pack_into("<Q", rgb, _RGB_PIXELS, scaled.ctypes.data)
+            struct.pack_into("<I", rgb, _RGB_ROWBYTES, w * ch * scaled.itemsize)
+            struct.pack_into("<I", rgb, _RGB_DEPTH, out_depth)
+            rc = L.avifImageRGBToYUV(image, rgb)
+            if rc != _RESULT_OK:
+                _fail(L, "ConvertFailed", rc)
+        except BaseException:
+            L.avifImageDestroy(image)
+            raise
+        self._image = image
+
+    def encode(self, o, q: int) -> bytes:
+        """avifEncoderCreate -> copyToEncoder -> quality -> AddImage(SINGLE) -> Finish (io.zig:619-635)."""
+        L = self._L
+        if self._image is None:
+            raise AvifBridgeError("AddImageFailed", "EncoderSource is closed")
         enc = L.avifEncoderCreate()
         if not enc:
             raise AvifBridgeError("OutOfMemory")
-        # copyToEncoder (parse_args.zig:65-74), then quality / qualityAlpha (io.zig:625-626)
-        ctypes.c_int32.from_address(enc + _ENC_SPEED).value = int(o.speed)
-        ctypes.c_int32.from_address(enc + _ENC_MAXTHREADS).value = int(o.max_threads)
-        ctypes.c_int32.from_address(enc + _ENC_TILEROWS).value = int(o.tile_rows_log2)
-        ctypes.c_int32.from_address(enc + _ENC_TILECOLS).value = int(o.tile_cols_log2)
-        ctypes.c_int32.from_address(enc + _ENC_AUTOTILING).value = 1 if o.auto_tiling else 0
-        rc = L.avifEncoderSetCodecSpecificOption(enc, b"tune", str(o.tune).encode())
-        if rc != _RESULT_OK:
-            _fail(L, "InvalidCodecOption", rc)
-        ctypes.c_int32.from_address(enc + _ENC_QUALITY).value = int(q)
-        ctypes.c_int32.from_address(enc + _ENC_QUALITYALPHA).value = int(o.quality_alpha)
-        rc = L.avifEncoderAddImage(enc, image, 1, _ADD_IMAGE_FLAG_SINGLE)
-        if rc != _RESULT_OK:
-            _fail(L, "AddImageFailed", rc)
-        rc = L.avifEncoderFinish(enc, ctypes.byref(out))
-        if rc != _RESULT_OK:
-            _fail(L, "FinishFailed", rc)
-        return ctypes.string_at(out.data, out.size)
-    finally:
-        if out.data:
-            L.avifRWDataFree(ctypes.byref(out))
-        if enc:
+        out = _RWData(None, 0)
+        try:
+            # copyToEncoder (parse_args.zig:65-74), then quality / qualityAlpha (io.zig:625-626)
+            ctypes.c_int32.from_address(enc + _ENC_SPEED).value = int(o.speed)
+            ctypes.c_int32.from_address(enc + _ENC_MAXTHREADS).value = int(o.max_threads)
+            ctypes.c_int32.from_address(enc + _ENC_TILEROWS).value = int(o.tile_rows_log2)
+            ctypes.c_int32.from_address(enc + _ENC_TILECOLS).value = int(o.tile_cols_log2)
+            ctypes.c_int32.from_address(enc + _ENC_AUTOTILING).value = 1 if o.auto_tiling else 0
+            rc = L.avifEncoderSetCodecSpecificOption(enc, b"tune", str(o.tune).encode())
+            if rc != _RESULT_OK:
+                _fail(L, "InvalidCodecOption", rc)
+            ctypes.c_int32.from_address(enc + _ENC_QUALITY).value = int(q)
+            ctypes.c_int32.from_address(enc + _ENC_QUALITYALPHA).value = int(o.quality_alpha)
+            rc = L.avifEncoderAddImage(enc, self._image, 1, _ADD_IMAGE_FLAG_SINGLE)
+            if rc != _RESULT_OK:
+                _fail(L, "AddImageFailed", rc)
+            rc = L.avifEncoderFinish(enc, ctypes.byref(out))
+            if rc != _RESULT_OK:
+                _fail(L, "FinishFailed", rc)
+            return ctypes.string_at(out.data, out.size)
+        finally:
+            if out.data:
+                L.avifRWDataFree(ctypes.byref(out))
             L.avifEncoderDestroy(enc)
-        L.avifImageDestroy(image)
+
+    def close(self) -> None:
+        if self._image is not None:
+            self._L.avifImageDestroy(self._image)
+            self._image = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def encode(scaled: np.ndarray, out_depth: int, o, q: int, icc: Optional[bytes] = None) -> bytes:
+    """io.encodeAvifToBuffer (io.zig:544-636) as the reference runs it: image, conversion and encode in one
+    call.  `scaled` = prescale_source(pixels, out_depth): (h, w, 3|4), uint8 for an 8-bit encode, uint16
+    holding 10-bit values for a 10-bit one.  `o` carries the fields of AvifEncOptions that copyToEncoder reads
+    (parse_args.zig:65-74) plus the CICP triple.  Callers that encode one source many times keep an
+    EncoderSource instead."""
+    with EncoderSource(scaled, out_depth, o, icc) as src:
+        return src.encode(o, q)
 
 
 class DecodedFrame:

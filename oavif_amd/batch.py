@@ -111,7 +111,7 @@ def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float 
         o = cli.AvifEncOptions()   # the reference's defaults (parse_args.zig:48-63): 1 thread, auto tiling
         o.speed, o.score_tgt, o.tolerance, o.max_pass = speed, score_tgt, tolerance, max_pass
     src = cli.load_source(str(path))
-    prepared = cli.encoder_input(src.pixels, o) if cli._bridge_on() else None   # hoisted out of the pass loop
+    prepared = cli.encoder_input(src.pixels, o, src.icc) if cli._bridge_on() else None   # hoisted out of the pass loop
     cache = {}
 
     def codec(q: int):
@@ -120,22 +120,26 @@ def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float 
         cache[q] = data                      # EncBuffer holds only the last probe (tq.zig:31-35)
         return cli._decode_rgb(data), len(data)
 
-    if cli._bridge_on():
-        from . import avif_bridge
+    try:
+        if cli._bridge_on():
+            from . import avif_bridge
 
-        def codec_frame(q: int):             # the decoded frame stays in libavif's buffer
-            data = cli._encode(src.pixels, o, q, icc=src.icc, prepared=prepared)
-            cache.clear()
-            cache[q] = data
-            return avif_bridge.decode_common(data), len(data)
-        r = tq.search_hip_frames(scorer, src.rgb, codec_frame, score_tgt=o.score_tgt, tolerance=o.tolerance,
-                                 max_pass=o.max_pass)
-    else:
-        r = tq.search_hip(scorer, src.rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
-                          max_pass=o.max_pass)
-    data = cache.get(r.q) if r.buf_q == r.q else None
-    if data is None:                         # main.zig:109-113: re-encode at the chosen q
-        data = cli._encode(src.pixels, o, r.q, icc=src.icc, prepared=prepared)
+            def codec_frame(q: int):             # the decoded frame stays in libavif's buffer
+                data = cli._encode(src.pixels, o, q, icc=src.icc, prepared=prepared)
+                cache.clear()
+                cache[q] = data
+                return avif_bridge.decode_common(data), len(data)
+            r = tq.search_hip_frames(scorer, src.rgb, codec_frame, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                                     max_pass=o.max_pass)
+        else:
+            r = tq.search_hip(scorer, src.rgb, codec, score_tgt=o.score_tgt, tolerance=o.tolerance,
+                              max_pass=o.max_pass)
+        data = cache.get(r.q) if r.buf_q == r.q else None
+        if data is None:                         # main.zig:109-113: re-encode at the chosen q
+            data = cli._encode(src.pixels, o, r.q, icc=src.icc, prepared=prepared)
+    finally:
+        if prepared is not None:
+            prepared.close()
     if out_path is not None:
         out_path.write_bytes(data)
     return r.q, r.score, r.num_pass, len(data)

@@ -344,13 +344,17 @@ def codec_depth(tenbit: bool, hbd: bool):
     return 10, None
 
 
-def encoder_input(pixels, o: AvifEncOptions):
-    """The source as avifImageRGBToYUV gets it, computed ONCE per image instead of on every pass (io.zig:566-617
-    recomputes it per pass; SURVEY.md 8f rank 4, the loops are oavif_prescale_* of the C ABI).  -> (scaled
-    (h, w, 3|4) u8 or u16-holding-10-bit, depth).  Gray sources are expanded to RGB(A): the reference hands
-    them to libavif as if they were RGB (io.zig:564), a row-stride bug this mirror does not reproduce."""
+def encoder_input(pixels, o: AvifEncOptions, icc=_USE_CLI_ICC):
+    """The source as the encoder gets it, made ONCE per image instead of on every pass: rescaled to the encoder's
+    depth (io.zig:566-617; SURVEY.md 8f rank 4, the loops are oavif_prescale_* of the C ABI), then wrapped,
+    tagged and converted to YUV444 (io.zig:550-623: avifImageCreate + avifImageRGBToYUV, 15 % of a 4K encode) --
+    only `quality` changes between the passes of a search (io.zig:625).  -> avif_bridge.EncoderSource.  Gray
+    sources are expanded to RGB(A): the reference hands them to libavif as if they were RGB (io.zig:564), a
+    row-stride bug this mirror does not reproduce."""
     import numpy as np
     from . import avif_bridge
+    if icc is _USE_CLI_ICC:
+        icc = _src_icc
     hbd = pixels.dtype == np.uint16
     depth, _note = codec_depth(o.tenbit, hbd)
     ch = pixels.shape[2]
@@ -358,18 +362,21 @@ def encoder_input(pixels, o: AvifEncOptions):
         pixels = np.repeat(pixels, 3, axis=2)
     elif ch == 2:
         pixels = np.concatenate([np.repeat(pixels[..., :1], 3, axis=2), pixels[..., 1:]], axis=2)
-    return avif_bridge.prescale_source(np.ascontiguousarray(pixels), depth), depth
+    scaled = avif_bridge.prescale_source(np.ascontiguousarray(pixels), depth)
+    return avif_bridge.EncoderSource(scaled, depth, o, icc)
 
 
 def _encode(src, o: AvifEncOptions, q: int, icc=_USE_CLI_ICC, prepared=None) -> bytes:
-    """io.encodeAvifToBuffer (io.zig:544-636).  `prepared` = encoder_input(src, o), hoisted by the callers that
-    encode one source many times."""
+    """io.encodeAvifToBuffer (io.zig:544-636).  `prepared` = encoder_input(src, o, icc), hoisted by the callers
+    that encode one source many times (then `src` and `icc` are not looked at again)."""
     from . import avif_bridge
     if icc is _USE_CLI_ICC:
         icc = _src_icc
     if avif_bridge.available():
-        scaled, depth = prepared if prepared is not None else encoder_input(src, o)
-        return avif_bridge.encode(scaled, depth, o, q, icc)
+        if prepared is not None:
+            return prepared.encode(o, q)
+        with encoder_input(src, o, icc) as once:
+            return once.encode(o, q)
     import io as _io
     from PIL import Image
     if src.dtype != "uint8":
@@ -414,6 +421,7 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         return 0
     own_scorer = False
     prefetched = None
+    prepared = None
     try:
         o, inp, out = parse_args(argv)
         if scorer is None and o.quality is None and inp is not None and out is not None:
@@ -514,6 +522,8 @@ def main(argv: Optional[List[str]] = None, scorer=None) -> int:
         eprint(f"error: {name}: {e}")
         return 1
     finally:
+        if prepared is not None:
+            prepared.close()
         if own_scorer and scorer is not None:
             scorer.close()
         elif prefetched is not None:

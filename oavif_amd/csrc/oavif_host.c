@@ -17,8 +17,8 @@
  *                     544-636), then the score of tq.zig:37 on the GPU through
  *                     ssimu2_score_against_reference_strided (libavif's RGB(A) rows as they are:
  *                     the copy loop of io.zig:654-663 never runs)
- *   io.zig:566-617    the source is rescaled to the encoder's depth ONCE (oavif_prescale_*), not
- *                     once per pass
+ *   io.zig:550-617    the source is rescaled to the encoder's depth (oavif_prescale_*) and converted to
+ *                     YUV444 ONCE, not once per pass (SURVEY.md 8f rank 4 and one step further)
  *
  * libavif: the image has a libavif 1.4.1 shared library (inside Pillow's wheel) and no header.
  * The leading members of the four public structs used here are declared below from the public
@@ -357,6 +357,7 @@ typedef struct {
     const Image* src;
     const void* scaled; /* the source at the encoder's depth, computed once */
     uint32_t out_depth;
+    avifImageHead* image; /* ... and as the encoder takes it (YUV444), converted once: make_source_image() */
     ssimu2_ctx* scorer;
     /* EncBuffer (main.zig:11-19): the AVIF bytes of the LAST probe */
     uint8_t* buf;
@@ -372,18 +373,23 @@ static double now_ms(void) {
     return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
-static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_size) { /* io.zig:544-636 */
+/* io.zig:550-623, hoisted out of the pass loop: the avifImage of the source -- created, tagged (CICP, ICC) and
+   converted to YUV444 -- is made ONCE.  The reference rebuilds it on every pass (avifImageCreate +
+   avifImageRGBToYUV over the whole frame, 15 % of a 4K encode at speed 9) although only `quality` changes between
+   passes (io.zig:625).  Same planes, same bitstream. */
+static int make_source_image(EncCtx* e) {
     const Options* o = e->o;
     const Image* s = e->src;
+    int r;
     avifImageHead* image = av.ImageCreate(s->w, s->h, e->out_depth, AVIF_YUV444);
     if (!image) return fail("OutOfMemory", NULL);
-    avifEncoderHead* enc = NULL;
-    avifRWData output = {NULL, 0};
-    int rc = -1, r;
     image->colorPrimaries = (uint16_t)o->color_primaries;
     image->transferCharacteristics = (uint16_t)o->transfer_characteristics;
     image->matrixCoefficients = (uint16_t)o->matrix_coefficients;
-    if (s->icc && av.ImageSetProfileICC(image, s->icc, s->icc_len) != AVIF_OK) { fail("SetICCProfileFailed", NULL); goto done; }
+    if (s->icc && av.ImageSetProfileICC(image, s->icc, s->icc_len) != AVIF_OK) {
+        av.ImageDestroy(image);
+        return fail("SetICCProfileFailed", NULL);
+    }
     avifRGBImage rgb;
     memset(&rgb, 0, sizeof rgb);
     av.RGBImageSetDefaults(&rgb, image);
@@ -391,7 +397,20 @@ static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_si
     rgb.pixels = (uint8_t*)(uintptr_t)e->scaled;
     rgb.rowBytes = s->w * s->channels * (e->out_depth > 8 ? 2u : 1u);
     rgb.depth = e->out_depth;
-    if ((r = av.ImageRGBToYUV(image, &rgb)) != AVIF_OK) { fail("ConvertFailed", av.ResultToString(r)); goto done; }
+    if ((r = av.ImageRGBToYUV(image, &rgb)) != AVIF_OK) {
+        av.ImageDestroy(image);
+        return fail("ConvertFailed", av.ResultToString(r));
+    }
+    e->image = image;
+    return 0;
+}
+
+static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_size) { /* io.zig:619-635 */
+    const Options* o = e->o;
+    avifEncoderHead* enc = NULL;
+    avifRWData output = {NULL, 0};
+    int rc = -1, r;
+    if (!e->image && make_source_image(e)) return -1;
     enc = av.EncoderCreate();
     if (!enc) { fail("OutOfMemory", NULL); goto done; }
     enc->qualityAlpha = o->quality_alpha; /* copyToEncoder (parse_args.zig:65-74) */
@@ -403,7 +422,7 @@ static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_si
     if (av.EncoderSetCodecSpecificOption(enc, "tune", o->tune) != AVIF_OK) { fail("InvalidCodecOption", NULL); goto done; }
     enc->quality = (int)q; /* io.zig:625-626 */
     enc->qualityAlpha = o->quality_alpha;
-    if ((r = av.EncoderAddImage(enc, image, 1, AVIF_ADD_IMAGE_FLAG_SINGLE)) != AVIF_OK) { fail("AddImageFailed", av.ResultToString(r)); goto done; }
+    if ((r = av.EncoderAddImage(enc, e->image, 1, AVIF_ADD_IMAGE_FLAG_SINGLE)) != AVIF_OK) { fail("AddImageFailed", av.ResultToString(r)); goto done; }
     if ((r = av.EncoderFinish(enc, &output)) != AVIF_OK) { fail("FinishFailed", av.ResultToString(r)); goto done; }
     *out = (uint8_t*)malloc(output.size);
     if (!*out) { fail("OutOfMemory", NULL); goto done; }
@@ -413,7 +432,6 @@ static int encode_to_buffer(EncCtx* e, uint32_t q, uint8_t** out, size_t* out_si
 done:
     if (output.data) av.RWDataFree(&output);
     if (enc) av.EncoderDestroy(enc);
-    av.ImageDestroy(image);
     return rc;
 }
 
@@ -476,6 +494,7 @@ typedef struct { /* everything run() allocates, released on every path */
 
 static void run_free(Run* r) {
     if (r->e.scorer) ssimu2_ctx_destroy(r->e.scorer);
+    if (r->e.image) av.ImageDestroy(r->e.image);
     free(r->e.buf);
     free(r->once);
     if (r->scaled != r->src.data) free(r->scaled);
@@ -519,10 +538,14 @@ static int run_inner(Run* r, int argc, char** argv) {
         uint16_t tiny[16 * 16 * 3];
         for (int i = 0; i < 16 * 16 * 3; ++i) tiny[i] = 512;
         Image ti = {16, 16, 3, 0, (uint8_t*)tiny, NULL, 0};
-        EncCtx pe = {&po, &ti, tiny, 10, NULL, NULL, 0, -1, 0, 0, 0};
+        EncCtx pe;
+        memset(&pe, 0, sizeof pe);
+        pe.o = &po; pe.src = &ti; pe.scaled = tiny; pe.out_depth = 10; pe.buf_q = -1;
         uint8_t* pb = NULL;
         size_t pn = 0;
-        if (encode_to_buffer(&pe, 50, &pb, &pn)) {
+        const int refused = encode_to_buffer(&pe, 50, &pb, &pn);
+        if (pe.image) av.ImageDestroy(pe.image);
+        if (refused) {
             out_depth = 8;
             depth_note = "note: the reference would write 10-bit here (--tenbit 1 / 16-bit source, io.zig:546-548); this "
                          "image's libaom has no high-bit-depth support, so the bitstream is 8-bit";

@@ -251,3 +251,30 @@ def test_hand_off_search_equals_tight_copy_search_on_the_device(scorer, alpha):
                                  tolerance=1.0)
         assert (a.q, a.score, a.num_pass, a.buf_q, a.history) == (b.q, b.score, b.num_pass, b.buf_q, b.history)
         assert a.last_avif_size == b.last_avif_size == len(enc(a.buf_q))
+
+
+def test_encoder_source_hoists_the_yuv_conversion_without_changing_a_byte():
+    """EncoderSource = io.zig:550-623 done once per image (avifImageCreate, CICP, ICC, avifImageRGBToYUV); every
+    encode from it equals the one-call form that rebuilds the image per pass, as the reference does -- also from
+    several threads at once (the probes of a speculative search share one source)."""
+    ref = synth.make_ref(160, 120, 14)
+    rgba = np.dstack([ref, np.tile(np.linspace(0, 255, 160, dtype=np.uint8), (120, 1))])
+    o = _opts(quality_alpha=70, color_primaries=1)
+    qs = [20, 45, 70, 95]
+    want = {q: ab.encode(rgba, 8, o, q) for q in qs}
+    with ab.EncoderSource(rgba, 8, o) as src:
+        assert (src.width, src.height, src.channels, src.depth) == (160, 120, 4, 8)
+        for q in qs + qs[::-1]:
+            assert src.encode(o, q) == want[q]
+        got = {}
+        ts = [threading.Thread(target=lambda q=q: got.__setitem__(q, src.encode(o, q))) for q in qs]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert got == want
+    with pytest.raises(ab.AvifBridgeError):
+        src.encode(o, 50)                               # closed
+    prepared = cli.encoder_input(rgba[..., :1], _opts(tenbit=False), None)   # gray -> RGB, made once
+    assert (prepared.channels, prepared.depth) == (3, 8)
+    assert cli._encode(None, _opts(tenbit=False), 50, icc=None, prepared=prepared) == \
+        ab.encode(np.repeat(rgba[..., :1], 3, axis=2), 8, _opts(tenbit=False), 50)
+    prepared.close()
