@@ -289,36 +289,81 @@ static uint8_t* read_file(const char* path, size_t* len) {
     return b;
 }
 
-/* io.loadPAM (io.zig:309-406): P7, WIDTH / HEIGHT / DEPTH / MAXVAL 255 / TUPLTYPE, ENDHDR */
+/* io.loadPAM (io.zig:309-406), the acceptance rules as oavif_amd/pam.py lists them: "P7"; the header ends at the
+   first "ENDHDR\n", else at the first blank line; lines split on CR / LF, '#' comments, keys matched as prefixes,
+   the first token after the key is the value; WIDTH, HEIGHT, DEPTH, MAXVAL all non-zero, MAXVAL 255, DEPTH 1..4;
+   TUPLTYPE GRAYSCALE / GRAYSCALE_ALPHA / RGB / RGB_ALPHA must agree with DEPTH, BLACKANDWHITE is refused, anything
+   else leaves DEPTH to decide; the raster must hold width*height*depth bytes.  Zig's error names. */
+static const uint8_t* find_bytes(const uint8_t* b, size_t n, const char* pat) {
+    const size_t m = strlen(pat);
+    for (size_t i = 0; i + m <= n; ++i)
+        if (memcmp(b + i, pat, m) == 0) return b + i;
+    return NULL;
+}
+static int pam_value(const char* rest, char* tok, size_t cap) { /* first whitespace-separated token; 0 = none */
+    while (*rest == ' ' || *rest == '\t') ++rest;
+    size_t k = 0;
+    while (*rest && *rest != ' ' && *rest != '\t' && k + 1 < cap) tok[k++] = *rest++;
+    tok[k] = 0;
+    return k > 0;
+}
+static int pam_usize(const char* tok, size_t* out) { /* std.fmt.parseInt(usize, tok, 10): digits, '_', a leading '+' */
+    size_t v = 0;
+    int digits = 0;
+    if (*tok == '+') ++tok;
+    for (; *tok; ++tok) {
+        if (*tok == '_') continue;
+        if (*tok < '0' || *tok > '9') return fail("InvalidCharacter", NULL);
+        if (v > (SIZE_MAX - 9) / 10) return fail("Overflow", NULL);
+        v = v * 10 + (size_t)(*tok - '0');
+        digits = 1;
+    }
+    if (!digits) return fail("InvalidCharacter", NULL);
+    *out = v;
+    return 0;
+}
 static int load_pam(const uint8_t* b, size_t n, Image* im) {
-    if (n < 3 || memcmp(b, "P7\n", 3) != 0) return fail("InvalidPAMHeader", NULL);
-    size_t p = 3;
-    long w = 0, h = 0, depth = 0, maxval = 0;
-    int ended = 0;
-    while (p < n && !ended) {
-        size_t e = p;
-        while (e < n && b[e] != '\n') ++e;
-        char line[128];
-        const size_t L = e - p < sizeof line - 1 ? e - p : sizeof line - 1;
+    if (n < 3 || b[0] != 'P' || b[1] != '7') return fail("NotAPamFile", NULL);
+    size_t header_end;
+    const uint8_t* e = find_bytes(b, n, "ENDHDR\n");
+    if (e) header_end = (size_t)(e - b) + 7;
+    else if ((e = find_bytes(b, n, "\n\n")) != NULL) header_end = (size_t)(e - b) + 2;
+    else return fail("HeaderNotFound", NULL);
+    size_t w = 0, h = 0, depth = 0, maxval = 0;
+    char tuple[64] = "UNSPECIFIED", tok[64];
+    for (size_t p = 0; p < header_end;) {
+        size_t q = p;
+        while (q < header_end && b[q] != '\n' && b[q] != '\r') ++q;
+        char line[160];
+        const size_t L = q - p < sizeof line - 1 ? q - p : sizeof line - 1;
         memcpy(line, b + p, L);
         line[L] = 0;
-        p = e + 1;
-        if (!strcmp(line, "ENDHDR") || !*line) ended = 1;
-        else if (!strncmp(line, "WIDTH ", 6)) w = atol(line + 6);
-        else if (!strncmp(line, "HEIGHT ", 7)) h = atol(line + 7);
-        else if (!strncmp(line, "DEPTH ", 6)) depth = atol(line + 6);
-        else if (!strncmp(line, "MAXVAL ", 7)) maxval = atol(line + 7);
+        p = q + 1;
+        if (!*line || *line == '#') continue;
+        if (!strncmp(line, "WIDTH", 5)) { if (pam_value(line + 5, tok, sizeof tok) && pam_usize(tok, &w)) return -1; }
+        else if (!strncmp(line, "HEIGHT", 6)) { if (pam_value(line + 6, tok, sizeof tok) && pam_usize(tok, &h)) return -1; }
+        else if (!strncmp(line, "DEPTH", 5)) { if (pam_value(line + 5, tok, sizeof tok) && pam_usize(tok, &depth)) return -1; }
+        else if (!strncmp(line, "MAXVAL", 6)) { if (pam_value(line + 6, tok, sizeof tok) && pam_usize(tok, &maxval)) return -1; }
+        else if (!strncmp(line, "TUPLTYPE", 8)) { if (pam_value(line + 8, tok, sizeof tok)) snprintf(tuple, sizeof tuple, "%s", tok); }
+        else if (!strcmp(line, "ENDHDR")) break;
     }
-    if (!ended || w <= 0 || h <= 0 || depth < 1 || depth > 4) return fail("InvalidPAMHeader", NULL);
-    if (maxval != 255) return fail("UnsupportedMaxval", NULL);
-    const size_t px = (size_t)w * (size_t)h;
-    if (n - p < px * (size_t)depth) return fail("UnexpectedEndOfFile", NULL);
+    if (!w || !h || !depth || !maxval) return fail("InvalidPamDimensions", NULL);
+    if (maxval != 255) return fail("UnsupportedPamMaxVal", NULL);
+    if (depth > 4) return fail("UnsupportedPamDepth", NULL);
+    static const struct { const char* name; size_t ch; } kinds[] = {
+        {"GRAYSCALE", 1}, {"GRAYSCALE_ALPHA", 2}, {"RGB", 3}, {"RGB_ALPHA", 4}};
+    for (size_t k = 0; k < 4; ++k)
+        if (!strcasecmp(tuple, kinds[k].name) && depth != kinds[k].ch) return fail("PamTupleMismatch", NULL);
+    if (!strcasecmp(tuple, "BLACKANDWHITE")) return fail("UnsupportedPamTuple", NULL);
+    if (w > 65536 || h > 65536) return fail("InsufficientDataInFile", NULL); /* no such raster fits the file anyway */
+    const size_t px = w * h;
+    if (px * depth > n - header_end) return fail("InsufficientDataInFile", NULL);
     /* gray (+alpha) is expanded to RGB(A): the reference hands 1- and 2-channel data to libavif as if it
        were RGB (io.zig:564), a row-stride bug this host does not reproduce */
     const uint32_t ch = depth <= 2 ? (uint32_t)depth + 2 : (uint32_t)depth;
     uint8_t* d = (uint8_t*)malloc(px * ch);
     if (!d) return fail("OutOfMemory", NULL);
-    const uint8_t* s = b + p;
+    const uint8_t* s = b + header_end;
     for (size_t i = 0; i < px; ++i)
         for (uint32_t c = 0; c < ch; ++c)
             d[i * ch + c] = depth >= 3 ? s[i * depth + c] : (c < 3 ? s[i * depth] : s[i * depth + 1]);

@@ -89,7 +89,30 @@ def test_argument_errors_carry_the_references_names(host, tmp_path):
         assert line in r.stderr
     bad = tmp_path / "bad.pam"
     bad.write_bytes(b"P7\nWIDTH 2\nHEIGHT 2\nDEPTH 3\nMAXVAL 65535\nTUPLTYPE RGB\nENDHDR\n" + bytes(24))
-    assert "error: UnsupportedMaxval" in _run(host, ["-q", "50", str(bad), "x.avif"]).stderr    # io.zig:368
+    assert "error: UnsupportedPamMaxVal" in _run(host, ["-q", "50", str(bad), "x.avif"]).stderr    # io.zig:369
+    # the PAM acceptance rules of io.zig:309-406, error for error as oavif_amd.pam (the Python mirror) raises them
+    body = bytes(2 * 2 * 4)
+    pams = {"NotAPamFile": b"P6\n2 2\n255\n" + body,
+            "HeaderNotFound": b"P7\nWIDTH 2\nHEIGHT 2\nDEPTH 3\nMAXVAL 255\n" + body.replace(b"\n", b"x"),
+            "InvalidPamDimensions": b"P7\nWIDTH 2\nDEPTH 3\nMAXVAL 255\nENDHDR\n" + body,
+            "UnsupportedPamDepth": b"P7\nWIDTH 1\nHEIGHT 1\nDEPTH 5\nMAXVAL 255\nENDHDR\n" + body,
+            "PamTupleMismatch": b"P7\nWIDTH 2\nHEIGHT 2\nDEPTH 3\nMAXVAL 255\nTUPLTYPE rgb_alpha\nENDHDR\n" + body,
+            "UnsupportedPamTuple": b"P7\nWIDTH 2\nHEIGHT 2\nDEPTH 1\nMAXVAL 255\nTUPLTYPE BLACKANDWHITE\nENDHDR\n" + body,
+            "InsufficientDataInFile": b"P7\nWIDTH 3\nHEIGHT 3\nDEPTH 4\nMAXVAL 255\nENDHDR\n" + body,
+            "InvalidCharacter": b"P7\nWIDTH 2x\nHEIGHT 2\nDEPTH 3\nMAXVAL 255\nENDHDR\n" + body}
+    for name, blob in pams.items():
+        f = tmp_path / f"{name}.pam"
+        f.write_bytes(blob)
+        with pytest.raises(pam.PamError) as pe:
+            pam.load_pam(blob)
+        assert pe.value.name == name
+        assert f"error: {name}" in _run(host, ["-q", "50", str(f), str(tmp_path / "x.avif")]).stderr, name
+    ok = tmp_path / "ok.pam"   # comments, CR LF, '+' and '_' in numbers, a blank-line header end, an unknown tuple type, trailing bytes
+    ok.write_bytes(b"P7\r\n# made by hand\r\nWIDTH +2\nHEIGHT 2_\nDEPTH 3\nMAXVAL 255 \nTUPLTYPE WHATEVER\n\n" + bytes(range(12)) + b"tail")
+    raster, w_, h_, ch_ = pam.load_pam(ok.read_bytes())
+    assert (w_, h_, ch_) == (2, 2, 3)
+    assert _run(host, ["-q", "50", "--tenbit", "0", str(ok), str(tmp_path / "ok.avif")]).returncode == 0
+    assert ab.probe((tmp_path / "ok.avif").read_bytes())["width"] == 2
     r = _run(host, ["-q", "50", str(png), str(tmp_path / "x.avif")], OAVIF_LIBAVIF="/nonexistent/libavif.so")
     assert r.returncode == 1 and "error: LibavifUnavailable" in r.stderr
 
