@@ -145,6 +145,26 @@ def encode_image(scorer, path: Path, out_path: Optional[Path], score_tgt: float 
     return r.q, r.score, r.num_pass, len(data)
 
 
+def exec_image(oavif_path: str, path: Path, out_path: Path, tolerance: Optional[float] = None, env=None):
+    """measure.py:41-107 for one file: run an `oavif` executable -- the reference's, or this repo's compiled
+    host (oavif_amd/lib/oavif_host) -- as `oavif [--tolerance T] <in> <out.avif>` and read the pass count off
+    its stderr with measure.py's own expression (measure.py:27).  q and score come from the same line
+    (main.zig:106); they are not in measure.py's CSV.  Returns (q, score, passes, final_bytes)."""
+    import re
+    import subprocess
+    cmd = [str(oavif_path)]
+    if tolerance is not None:
+        cmd += ["--tolerance", str(tolerance)]
+    cmd += [str(path), str(out_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    if r.returncode != 0:   # measure.py:94: check=True -> CalledProcessError
+        raise RuntimeError(f"Command {cmd!r} returned non-zero exit status {r.returncode}: {(r.stderr or '').strip()[-300:]}")
+    m = re.search(r"(\d+)\s+passes?", r.stderr or "", re.IGNORECASE)
+    f = re.search(r"Found q(\d+) \(score (-?\d+(?:\.\d+)?)", r.stderr or "")
+    final_bytes = out_path.stat().st_size if out_path.exists() else None
+    return (int(f.group(1)) if f else 0, float(f.group(2)) if f else 0.0, int(m.group(1)) if m else -1, final_bytes)
+
+
 def output_names(image_files: Sequence[Path]) -> List[str]:
     """One .avif name per input: `<stem>.avif` as measure.py writes it (measure.py:49), or
     `<stem>_<ext>.avif` for inputs whose stem is shared (a.png + a.jpg); a name that is still
@@ -382,13 +402,21 @@ def parse_cli(argv=None):
                     help="ranks that share one GPU (launch nproc-per-node = GPUs x this): the CPU codec is the "
                          "cost of a pass and several processes per GPU use the host's cores better than one "
                          "process with as many threads; the gather of such a job runs over gloo")
+    ap.add_argument("--exec", dest="exec_oavif", action="store_true",
+                    help="run OAVIF_PATH once per image exactly as measure.py does (measure.py:41-107), in this rank's "
+                         "shard and on this rank's GPU (LOCAL_RANK is handed to the child), instead of searching in "
+                         "this process: e.g. oavif_amd/lib/oavif_host, the compiled C host of this repository")
     ap.add_argument("--out-dir", default="temp_avif_output")
     args = ap.parse_args(argv)
+    args.oavif_path = None
     if len(args.paths) == 2:
         args.images_dir, args.output_csv = args.paths
+        if args.exec_oavif:
+            ap.error("--exec needs OAVIF_PATH: IMAGES_DIR OAVIF_PATH OUTPUT_CSV")
     elif len(args.paths) == 3:   # measure.py:111-123
         args.images_dir, oavif_path, args.output_csv = args.paths
-        if int(os.environ.get("RANK", "0")) == 0:
+        args.oavif_path = oavif_path
+        if int(os.environ.get("RANK", "0")) == 0 and not args.exec_oavif:
             print(f"note: {oavif_path} is not run; the search runs in this process on the GPU scorer",
                   file=sys.stderr)
     else:
@@ -466,7 +494,18 @@ def main(argv=None) -> int:
 
     names = output_names(files)
 
+    child_env = None
+    if args.exec_oavif:
+        from . import avif_bridge
+        child_env = dict(os.environ, LOCAL_RANK=str(local_rank))        # the child scores on this rank's GPU
+        if "OAVIF_LIBAVIF" not in child_env and avif_bridge._find_library():
+            child_env["OAVIF_LIBAVIF"] = avif_bridge._find_library()    # the C host opens libavif by this name
+
     def encode_fn(i, path):
+        if args.exec_oavif:
+            q, score, passes, nbytes = exec_image(args.oavif_path, path, out_dir / names[i],
+                                                  None if args.tolerance == 2.0 else args.tolerance, child_env)
+            return q, score, (passes if passes >= 0 else 0), nbytes
         if not hasattr(tls, "scorer"):  # one context (HIP stream + scratch) per worker thread
             from . import cli
             tls.scorer = Ssimu2(local_rank, blur=cli.blur_from_env())

@@ -352,3 +352,45 @@ def test_batch_and_cli_share_one_encode_path_and_keep_alpha(tmp_path, monkeypatc
     assert Image.open(io.BytesIO(out.read_bytes())).mode == "RGBA"
     assert cli.main(["-q", "61", str(src), str(tmp_path / "cli.avif")]) == 0
     assert (tmp_path / "cli.avif").read_bytes() == out.read_bytes()
+
+
+def test_exec_mode_runs_an_oavif_binary_per_image_like_measure_py(tmp_path):
+    """`--exec`: measure.py:41-107 -- one `oavif [--tolerance T] <in> <out>` process per image, the pass count read
+    off stderr with measure.py's own expression, a failing image recorded and the batch continued."""
+    import stat
+    fake = tmp_path / "oavif"
+    fake.write_text("""#!/usr/bin/env python3
+import sys
+args = sys.argv[1:]
+tol = None
+if args[:1] == ["--tolerance"]:
+    tol, args = args[1], args[2:]
+src, out = args
+sys.stderr.write("\\x1b[31moavif\\x1b[0m | fake\\n")
+if "bad" in src:
+    sys.stderr.write("error: DecodeFailed\\n")
+    sys.exit(1)
+n = 1 if "one" in src else 3
+sys.stderr.write(f"Read 8x8, RGB, 8-bit, 10 bytes\\nFound q{40 + n} (score {79.5 + n:.2f}, {n} passes)\\n")   # main.zig:106 prints "passes" for 1 too
+open(out, "wb").write(b"x" * (100 * n + (7 if tol else 0)))
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    files = []
+    for name in ("a_one.png", "b_bad.png", "c.png"):
+        p = tmp_path / name
+        p.write_bytes(b"0" * 1000)
+        files.append(p)
+    out = tmp_path / "o"
+    out.mkdir()
+    assert batch.exec_image(str(fake), files[0], out / "a.avif") == (41, 80.5, 1, 100)        # "1 passes" (main.zig:106; measure.py:27's expression needs the "e")
+    assert batch.exec_image(str(fake), files[2], out / "c.avif", tolerance=1.5) == (43, 82.5, 3, 307)
+    with pytest.raises(RuntimeError) as e:
+        batch.exec_image(str(fake), files[1], out / "b.avif")
+    assert "non-zero exit status 1" in str(e.value) and "DecodeFailed" in str(e.value)
+    res = batch.run_batch(files, lambda i, p: batch.exec_image(str(fake), p, out / f"{p.stem}.avif"), 0, 1)
+    assert [(r.status, r.passes, r.final_bytes) for r in res] == [("ok", 1, 100), ("error", None, None), ("ok", 3, 300)]
+    assert (res[0].q, res[2].q) == (41, 43)
+    args = batch.parse_cli([str(tmp_path), str(fake), str(tmp_path / "r.csv"), "--exec"])
+    assert args.exec_oavif and args.oavif_path == str(fake)
+    with pytest.raises(SystemExit):
+        batch.parse_cli([str(tmp_path), str(tmp_path / "r.csv"), "--exec"])

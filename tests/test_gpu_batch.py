@@ -124,3 +124,33 @@ print("rccl gather ok")
         assert q.returncode == 0, q.stderr[-2000:]
         outs.append(_rows(csv_path))
     assert outs[0] == outs[1] and len(outs[0][1]) == 4
+
+
+def test_exec_mode_with_the_compiled_host_equals_the_in_process_batch(tmp_path):
+    """`--exec`: the batch as measure.py runs it (measure.py:151-158: one `oavif` process per image) with this
+    repository's compiled C host as the `oavif` binary, against the in-process batch: the same CSV -- bytes,
+    passes, status -- for every image (both run the reference's libavif calls and the same search and scorer)."""
+    from PIL import Image
+    from oavif_amd import build as obuild
+    if obuild.host_needs_build():
+        obuild.build_host()
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    for k, (w, h) in enumerate(((320, 240), (257, 199), (400, 300), (192, 144))):
+        a = synth.make_ref(w, h, 40 + k)
+        if k == 2:   # an RGBA source: alpha reaches the encoder, not the scorer
+            a = np.dstack([a, np.tile(np.linspace(0, 255, w, dtype=np.uint8), (h, 1))])
+        Image.fromarray(a).save(img_dir / f"img_{k}.png")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    runs = {}
+    for tag, extra in (("inproc", []), ("exec", [obuild.HOST_PATH, "--exec"])):
+        out = tmp_path / f"{tag}.csv"
+        cmd = [sys.executable, "-m", "oavif_amd.batch", str(img_dir)] + extra[:1] + [str(out)] + extra[1:] + \
+              ["--workers", "2", "--tolerance", "1.5", "--out-dir", str(tmp_path / f"o_{tag}"), "--keep"]
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[tag] = _rows(out)
+        assert "Images: 4 ok, 0 no-output, 0 errors" in p.stdout
+    assert runs["exec"] == runs["inproc"]
+    for k in range(4):
+        assert (tmp_path / "o_exec" / f"img_{k}.avif").read_bytes() == (tmp_path / "o_inproc" / f"img_{k}.avif").read_bytes()
