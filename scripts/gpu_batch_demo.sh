@@ -14,8 +14,8 @@ for w in 1 16; do
   echo "== workers=$w"
   python -m oavif_amd.batch $D/imgs $D/out_$w.csv --workers $w --out-dir $D/o$w 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average encoding|Average passes|Host cores"
 done
-echo "== --exec: one process per image, as scripts/measure.py runs an oavif binary (measure.py:151-158), with this repository's compiled C host (oavif_amd/lib/oavif_host) as that binary; then the same with 16 at a time"
-for w in 1 16; do
+echo "== --exec: one process per image, as scripts/measure.py runs an oavif binary (measure.py:151-158), with this repository's compiled C host (oavif_amd/lib/oavif_host) as that binary; then the same with 4 at a time (this pool allows a job 6 processes on a GPU at once)"
+for w in 1 4; do
   python -m oavif_amd.batch $D/imgs $GRAFT_REPO_ROOT/oavif_amd/lib/oavif_host $D/out_x$w.csv --exec --workers $w --out-dir $D/ox$w 2>/dev/null | grep -E "Images:|Total wall|Throughput|Average encoding"
 done
 echo "== workers=default, FIR blur mode (OAVIF_SSIMU2_BLUR=fir; the runs above and below use the search path's default, the published recursion)"
@@ -31,6 +31,6 @@ a = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_1.csv"))]
 b = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_16.csv"))]
 c = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_2r.csv"))]
 d = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_4r.csv"))]
-x = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_x16.csv"))]
+x = [(r[0], r[2], r[6]) for r in csv.reader(open("$D/out_x4.csv"))]
 print("identical results (1 worker, 16 workers, 2 ranks, 4 ranks, one C-host process per image):", a == b == c == d == x)
 PY
