@@ -92,7 +92,7 @@ def build_host(verbose: bool = False) -> str:
     inc = os.path.join(os.path.dirname(_HERE), "include")
     tmp = HOST_PATH + f".tmp{os.getpid()}"
     cmd = [os.environ.get("CC", "gcc"), "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I", inc,
-           os.path.join(CSRC, "oavif_host.c"), "-o", tmp, "-L", LIB_DIR, "-loavif_hip", "-ldl", "-lm",
+           os.path.join(CSRC, "oavif_host.c"), "-o", tmp, "-L", LIB_DIR, "-loavif_hip", "-ldl", "-lm", "-lpthread",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -35,6 +35,7 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <math.h>
+#include <pthread.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -113,11 +114,16 @@ static struct {
     int (*DecoderNextImage)(avifDecoderHead*);
 } av;
 
-static const char* g_err = NULL; /* the reference's Zig error name of the failure */
+static const char* g_err = NULL; /* the reference's Zig error name of the failure (the first one: probes may run on threads) */
 static char g_detail[320];
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static int fail(const char* name, const char* detail) {
-    g_err = name;
-    snprintf(g_detail, sizeof g_detail, "%s", detail ? detail : "");
+    pthread_mutex_lock(&g_lock);
+    if (!g_err) {
+        g_err = name;
+        snprintf(g_detail, sizeof g_detail, "%s", detail ? detail : "");
+    }
+    pthread_mutex_unlock(&g_lock);
     return -1;
 }
 
@@ -480,14 +486,15 @@ done:
     return rc;
 }
 
-static int probe(void* user, uint32_t q, double* out_score) { /* computeScoreAtQuality (tq.zig:21-38) */
-    EncCtx* e = (EncCtx*)user;
+/* One pass (computeScoreAtQuality, tq.zig:21-38) on a given scorer context: encode at q, decode, score.  Touches
+   nothing shared but the read-only source image, so the probes of a speculative wave run it on threads. */
+static int pass_on(const EncCtx* e, ssimu2_ctx* scorer, uint32_t q, uint8_t** out_avif, size_t* out_size,
+                   double* out_score, double times_ms[3]) {
     uint8_t* avif = NULL;
     size_t avif_size = 0;
     double t0 = now_ms();
-    if (encode_to_buffer(e, q, &avif, &avif_size)) return -1;
+    if (encode_to_buffer((EncCtx*)(uintptr_t)e, q, &avif, &avif_size)) return -1; /* e->image exists: read-only use */
     double t1 = now_ms();
-    e->encode_ms += t1 - t0;
     /* decodeAvifCommon(avif, use_8bit = true) (io.zig:452-482) */
     int rc = -1, r;
     avifDecoderHead* dec = av.DecoderCreate();
@@ -505,20 +512,94 @@ static int probe(void* user, uint32_t q, double* out_score) { /* computeScoreAtQ
     if (av.RGBImageAllocatePixels(&rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
     if ((r = av.ImageYUVToRGB(img, &rgb)) != AVIF_OK) { fail("ConvertToRGBFailed", av.ResultToString(r)); goto done; }
     double t2 = now_ms();
-    e->decode_ms += t2 - t1;
-    /* tq.zig:31-35: the buffer of this probe replaces the previous one */
-    free(e->buf);
-    e->buf = avif; e->buf_size = avif_size; e->buf_q = (int)q;
-    avif = NULL;
     /* tq.zig:37, without the copy loop of io.zig:654-663: libavif's rows as they are */
-    r = ssimu2_score_against_reference_strided(e->scorer, rgb.pixels, rgb.rowBytes, rgb.format == AVIF_RGBA ? 4 : 3, out_score);
-    e->score_ms += now_ms() - t2;
-    if (r != SSIMU2_OK) { fail("ScorerFailed", ssimu2_last_error(e->scorer)); goto done; }
+    r = ssimu2_score_against_reference_strided(scorer, rgb.pixels, rgb.rowBytes, rgb.format == AVIF_RGBA ? 4 : 3, out_score);
+    if (r != SSIMU2_OK) { fail("ScorerFailed", ssimu2_last_error(scorer)); goto done; }
+    times_ms[0] = t1 - t0; times_ms[1] = t2 - t1; times_ms[2] = now_ms() - t2;
+    *out_avif = avif; *out_size = avif_size;
+    avif = NULL;
     rc = 0;
 done:
     if (rgb.pixels) av.RGBImageFreePixels(&rgb);
     if (dec) av.DecoderDestroy(dec);
     free(avif);
+    return rc;
+}
+
+static int probe(void* user, uint32_t q, double* out_score) { /* the sequential search's pass */
+    EncCtx* e = (EncCtx*)user;
+    uint8_t* avif = NULL;
+    size_t n = 0;
+    double t[3];
+    if (pass_on(e, e->scorer, q, &avif, &n, out_score, t)) return -1;
+    e->encode_ms += t[0]; e->decode_ms += t[1]; e->score_ms += t[2];
+    free(e->buf); /* tq.zig:31-35: the buffer of this probe replaces the previous one */
+    e->buf = avif; e->buf_size = n; e->buf_q = (int)q;
+    return 0;
+}
+
+/* ---- the probes of one search fanned over scorer contexts and host threads (BASELINE
+   configs[2]): oavif_tq_find_target_quality_speculative asks for waves of quantizers, each probe of a wave runs
+   the pass above on its own context (= its own HIP stream) and thread.  OAVIF_PROBE_FANOUT=N, as the Python
+   mirror; the result is the sequential search's (include/oavif_tq.h). ------------------------------------------ */
+typedef struct {
+    EncCtx* e;
+    const uint8_t* rgb8;
+    int blur;
+    uint32_t fan;
+    ssimu2_ctx* ctx[OAVIF_TQ_MAX_FANOUT];
+    int have_ref[OAVIF_TQ_MAX_FANOUT]; /* a context gets the reference when a wave first uses it */
+    struct { int q; uint8_t* b; size_t n; } kept[OAVIF_TQ_MAX_PASS * OAVIF_TQ_MAX_FANOUT]; /* every probe's bytes: any may be the answer */
+    int nkept;
+} Spec;
+typedef struct { Spec* s; uint32_t slot, q; double score; int rc; } SpecJob;
+
+static void* spec_job(void* arg) {
+    SpecJob* j = (SpecJob*)arg;
+    Spec* s = j->s;
+    j->rc = -1;
+    if (!s->have_ref[j->slot]) { /* a slot is used by one thread at a time */
+        if (ssimu2_ctx_set_blur(s->ctx[j->slot], s->blur) || ssimu2_set_reference(s->ctx[j->slot], s->rgb8, s->e->src->w, s->e->src->h)) {
+            fail("ScorerFailed", ssimu2_last_error(s->ctx[j->slot]));
+            return NULL;
+        }
+        s->have_ref[j->slot] = 1;
+    }
+    uint8_t* avif = NULL;
+    size_t n = 0;
+    double t[3];
+    if (pass_on(s->e, s->ctx[j->slot], j->q, &avif, &n, &j->score, t)) return NULL;
+    pthread_mutex_lock(&g_lock);
+    s->e->encode_ms += t[0]; s->e->decode_ms += t[1]; s->e->score_ms += t[2];
+    if (s->nkept < (int)(sizeof s->kept / sizeof s->kept[0])) {
+        s->kept[s->nkept].q = (int)j->q; s->kept[s->nkept].b = avif; s->kept[s->nkept].n = n;
+        ++s->nkept;
+        avif = NULL;
+    }
+    pthread_mutex_unlock(&g_lock);
+    free(avif);
+    j->rc = 0;
+    return NULL;
+}
+
+static int spec_batch(void* user, const uint32_t* qs, uint32_t n, double* out_scores) {
+    Spec* s = (Spec*)user;
+    SpecJob jobs[OAVIF_TQ_MAX_FANOUT];
+    pthread_t th[OAVIF_TQ_MAX_FANOUT];
+    int started[OAVIF_TQ_MAX_FANOUT] = {0};
+    if (n > s->fan) return fail("SearchFailed", "wave larger than the fan-out");
+    for (uint32_t i = 0; i < n; ++i) {
+        jobs[i].s = s; jobs[i].slot = i; jobs[i].q = qs[i]; jobs[i].score = 0; jobs[i].rc = -1;
+        if (i + 1 == n) spec_job(&jobs[i]); /* the last probe of a wave runs on the calling thread */
+        else started[i] = pthread_create(&th[i], NULL, spec_job, &jobs[i]) == 0;
+        if (i + 1 < n && !started[i]) spec_job(&jobs[i]);
+    }
+    int rc = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (started[i]) pthread_join(th[i], NULL);
+        if (jobs[i].rc) rc = -1;
+        out_scores[i] = jobs[i].score;
+    }
     return rc;
 }
 
@@ -535,9 +616,13 @@ typedef struct { /* everything run() allocates, released on every path */
     void* scaled;
     EncCtx e;
     uint8_t* once;
+    Spec spec;
 } Run;
 
 static void run_free(Run* r) {
+    for (uint32_t i = 1; i < OAVIF_TQ_MAX_FANOUT; ++i)
+        if (r->spec.ctx[i]) ssimu2_ctx_destroy(r->spec.ctx[i]);
+    for (int k = 0; k < r->spec.nkept; ++k) free(r->spec.kept[k].b);
     if (r->e.scorer) ssimu2_ctx_destroy(r->e.scorer);
     if (r->e.image) av.ImageDestroy(r->e.image);
     free(r->e.buf);
@@ -640,8 +725,31 @@ static int run_inner(Run* r, int argc, char** argv) {
         return fail("ScorerFailed", ssimu2_last_error(e->scorer));
     oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
     oavif_tq_result res;
-    rc = oavif_tq_find_target_quality(&to, probe, e, &res);
-    if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
+    const int fan = getenv("OAVIF_PROBE_FANOUT") ? atoi(getenv("OAVIF_PROBE_FANOUT")) : 1;
+    if (fan > 1) { /* not a CLI flag: the option surface stays the reference's (parse_args.zig:76-122) */
+        if (make_source_image(e)) return -1; /* before the first wave: the threads only read it */
+        Spec* sp = &r->spec;
+        sp->e = e; sp->rgb8 = r->rgb8; sp->blur = mode;
+        sp->fan = fan > OAVIF_TQ_MAX_FANOUT ? OAVIF_TQ_MAX_FANOUT : (uint32_t)fan;
+        sp->ctx[0] = e->scorer;
+        sp->have_ref[0] = 1;
+        for (uint32_t i = 1; i < sp->fan; ++i) /* contexts are made here, on one thread; each is one HIP stream + scratch */
+            if (ssimu2_ctx_create(device, NULL, &sp->ctx[i]) != SSIMU2_OK) return fail("ScorerFailed", ssimu2_last_error(NULL));
+        oavif_tq_spec_options so = OAVIF_TQ_SPEC_OPTIONS_INIT(sp->fan, 1);
+        oavif_tq_spec_stats st;
+        rc = oavif_tq_find_target_quality_speculative(&to, &so, spec_batch, sp, &res, &st);
+        if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
+        for (int k = 0; k < sp->nkept; ++k)
+            if (sp->kept[k].q == (int)res.q && !e->buf) { /* EncBuffer: here the bytes of the chosen q, if it was probed */
+                e->buf = sp->kept[k].b; e->buf_size = sp->kept[k].n; e->buf_q = sp->kept[k].q;
+                sp->kept[k].b = NULL;
+            }
+        if (getenv("OAVIF_HOST_TIMES"))
+            fprintf(stderr, "speculative: %u waves, %u probes issued, %u cache hits\n", st.waves, st.probes_issued, st.cache_hits);
+    } else {
+        rc = oavif_tq_find_target_quality(&to, probe, e, &res);
+        if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
+    }
     fprintf(stderr, "Found q%u (score %.2f, %u passes)\n", res.q, res.score, res.num_pass);
     if (e->buf_q == (int)res.q) { /* main.zig:109-113 */
         if (write_file(out, e->buf, e->buf_size)) return -1;

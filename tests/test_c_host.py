@@ -145,6 +145,15 @@ def test_search_end_to_end_equals_the_python_mirror(host, tmp_path, capsys, monk
         assert m and re.search(r"(\d+)\s+passes?", cerr[3]).group(1) == m.group(3)      # measure.py:27
         assert cerr[-1].startswith("times: encode ")
         assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
+        # the same search with its probes fanned over 4 scorer contexts and threads (BASELINE configs[2];
+        # oavif_tq_find_target_quality_speculative from compiled code): the sequential search's result
+        f = _run(host, [*args, str(src), str(tmp_path / "f.avif")], OAVIF_SSIMU2_BLUR=blur, OAVIF_HOST_TIMES="1",
+                 OAVIF_PROBE_FANOUT="4")
+        assert f.returncode == 0, f.stderr
+        ferr = f.stderr.splitlines()
+        assert ferr[1:5] == cerr[1:5], (ferr, cerr)
+        assert any(l.startswith("speculative: ") for l in ferr)
+        assert (tmp_path / "f.avif").read_bytes() == (tmp_path / "c.avif").read_bytes()
 
 
 def test_host_is_clean_under_sanitizers(tmp_path, hip_lib):
@@ -160,7 +169,7 @@ def test_host_is_clean_under_sanitizers(tmp_path, hip_lib):
     exe = str(tmp_path / "host_san")
     subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=gnu11",
                     "-I", os.path.join(root, "include"), os.path.join(root, "oavif_amd", "csrc", "oavif_host.c"),
-                    "-o", exe, "-L", libdir, "-loavif_hip", "-ldl", "-lm", f"-Wl,-rpath,{libdir}",
+                    "-o", exe, "-L", libdir, "-loavif_hip", "-ldl", "-lm", "-lpthread", f"-Wl,-rpath,{libdir}",
                     "-Wl,-rpath-link,/opt/rocm/lib"], check=True, capture_output=True)
     _ref, png, p = _inputs(tmp_path, 96, 64)
     raw = png.read_bytes()
