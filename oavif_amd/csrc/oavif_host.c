@@ -633,6 +633,11 @@ static void run_free(Run* r) {
     free(r->src.icc);
 }
 
+static double g_t0;
+static void phase(const char* what) { /* OAVIF_HOST_TIMES: where a one-image run spends its wall time */
+    if (getenv("OAVIF_HOST_TIMES")) fprintf(stderr, "  [%7.1f ms] %s\n", now_ms() - g_t0, what);
+}
+
 static int run_inner(Run* r, int argc, char** argv) {
     Options o = {0, 9, 1, 0, 0, 1, 80.0, 1, "iq", 2.0, 6, -1, 2, 2, 2}; /* parse_args.zig:48-63 */
     const char *in = NULL, *out = NULL;
@@ -640,9 +645,12 @@ static int run_inner(Run* r, int argc, char** argv) {
     if (!in || !out) return fail("MissingInputOrOutput", NULL);
     const int device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
     if (o.quality < 0) ssimu2_prefetch(device); /* the HIP start-up runs behind the image load and the first encode */
+    phase("arguments parsed, scorer start-up begun in the background");
     if (load_libavif()) return -1;
+    phase("libavif opened and checked");
     Image* src = &r->src;
     if (load_image(in, src)) return -1;
+    phase("image loaded");
     struct stat st;
     memset(&st, 0, sizeof st);
     stat(in, &st);
@@ -713,8 +721,11 @@ static int run_inner(Run* r, int argc, char** argv) {
         fprintf(stderr, "Searching [tgt %.0f±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
     else
         fprintf(stderr, "Searching [tgt %g±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
+    if (make_source_image(e)) return -1; /* the CPU side of the first pass's set-up overlaps the scorer's start-up */
+    phase("source converted to YUV444");
     int rc = ssimu2_ctx_create(device, NULL, &e->scorer);
     if (rc != SSIMU2_OK) return fail(rc == SSIMU2_ERR_NO_DEVICE ? "NoDevice" : "ScorerFailed", ssimu2_last_error(NULL));
+    phase("scorer context created");
     /* the blur of the search path: the published recursion unless OAVIF_SSIMU2_BLUR says otherwise (as the
        Zig shim's `blur` and the Python mirror: INTEGRATION.md section 2e) */
     const char* bm = getenv("OAVIF_SSIMU2_BLUR");
@@ -723,6 +734,7 @@ static int run_inner(Run* r, int argc, char** argv) {
     else if (bm && (!strcmp(bm, "recursive_fma") || !strcmp(bm, "iir_fma"))) mode = SSIMU2_BLUR_RECURSIVE_FMA;
     if ((rc = ssimu2_ctx_set_blur(e->scorer, mode)) || (rc = ssimu2_set_reference(e->scorer, r->rgb8, src->w, src->h)))
         return fail("ScorerFailed", ssimu2_last_error(e->scorer));
+    phase("reference uploaded and cached");
     oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
     oavif_tq_result res;
     const int fan = getenv("OAVIF_PROBE_FANOUT") ? atoi(getenv("OAVIF_PROBE_FANOUT")) : 1;
@@ -750,6 +762,7 @@ static int run_inner(Run* r, int argc, char** argv) {
         rc = oavif_tq_find_target_quality(&to, probe, e, &res);
         if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
     }
+    phase("search done");
     fprintf(stderr, "Found q%u (score %.2f, %u passes)\n", res.q, res.score, res.num_pass);
     if (e->buf_q == (int)res.q) { /* main.zig:109-113 */
         if (write_file(out, e->buf, e->buf_size)) return -1;
@@ -769,8 +782,11 @@ static int run_inner(Run* r, int argc, char** argv) {
 static int run(int argc, char** argv) {
     Run r;
     memset(&r, 0, sizeof r);
+    g_t0 = now_ms();
     const int rc = run_inner(&r, argc, argv);
+    phase("output written");
     run_free(&r);
+    phase("contexts and buffers released");
     return rc;
 }
 
