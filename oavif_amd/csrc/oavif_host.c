@@ -42,6 +42,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "oavif_tq.h"
 #include "ssimu2_hip.h"
@@ -409,7 +410,9 @@ typedef struct {
     const void* scaled; /* the source at the encoder's depth, computed once */
     uint32_t out_depth;
     avifImageHead* image; /* ... and as the encoder takes it (YUV444), converted once: make_source_image() */
-    ssimu2_ctx* scorer;
+    ssimu2_ctx* scorer; /* made when the first score needs it (ensure_scorer) */
+    int device, blur;
+    const uint8_t* rgb8; /* e.rgb: the scorer's reference */
     /* EncBuffer (main.zig:11-19): the AVIF bytes of the LAST probe */
     uint8_t* buf;
     size_t buf_size;
@@ -486,52 +489,77 @@ done:
     return rc;
 }
 
-/* One pass (computeScoreAtQuality, tq.zig:21-38) on a given scorer context: encode at q, decode, score.  Touches
-   nothing shared but the read-only source image, so the probes of a speculative wave run it on threads. */
-static int pass_on(const EncCtx* e, ssimu2_ctx* scorer, uint32_t q, uint8_t** out_avif, size_t* out_size,
-                   double* out_score, double times_ms[3]) {
+/* One pass (computeScoreAtQuality, tq.zig:21-38) in two halves: the CPU half (encode at q, decode to libavif's
+   8-bit RGB(A) rows) touches nothing shared but the read-only source image, so the probes of a speculative wave
+   run it on threads and the FIRST pass of a run runs it while the scorer is still starting up; the GPU half
+   scores those rows on a given context. */
+typedef struct { avifDecoderHead* dec; avifRGBImage rgb; } Decoded;
+static void decoded_free(Decoded* d) {
+    if (d->rgb.pixels) av.RGBImageFreePixels(&d->rgb);
+    if (d->dec) av.DecoderDestroy(d->dec);
+    memset(d, 0, sizeof *d);
+}
+static int pass_cpu(const EncCtx* e, uint32_t q, uint8_t** out_avif, size_t* out_size, Decoded* d, double times_ms[3]) {
     uint8_t* avif = NULL;
     size_t avif_size = 0;
+    memset(d, 0, sizeof *d);
     double t0 = now_ms();
     if (encode_to_buffer((EncCtx*)(uintptr_t)e, q, &avif, &avif_size)) return -1; /* e->image exists: read-only use */
     double t1 = now_ms();
     /* decodeAvifCommon(avif, use_8bit = true) (io.zig:452-482) */
     int rc = -1, r;
-    avifDecoderHead* dec = av.DecoderCreate();
-    avifRGBImage rgb;
-    memset(&rgb, 0, sizeof rgb);
-    if (!dec) { fail("OutOfMemory", NULL); goto done; }
-    if (av.DecoderSetIOMemory(dec, avif, avif_size) != AVIF_OK) { fail("SetIOFailed", NULL); goto done; }
-    if ((r = av.DecoderParse(dec)) != AVIF_OK) { fail("ParseFailed", av.ResultToString(r)); goto done; }
-    if ((r = av.DecoderNextImage(dec)) != AVIF_OK) { fail("DecodeImageFailed", av.ResultToString(r)); goto done; }
-    const avifImageHead* img = dec->image;
+    d->dec = av.DecoderCreate();
+    if (!d->dec) { fail("OutOfMemory", NULL); goto done; }
+    if (av.DecoderSetIOMemory(d->dec, avif, avif_size) != AVIF_OK) { fail("SetIOFailed", NULL); goto done; }
+    if ((r = av.DecoderParse(d->dec)) != AVIF_OK) { fail("ParseFailed", av.ResultToString(r)); goto done; }
+    if ((r = av.DecoderNextImage(d->dec)) != AVIF_OK) { fail("DecodeImageFailed", av.ResultToString(r)); goto done; }
+    const avifImageHead* img = d->dec->image;
     if (!img || img->width != e->src->w || img->height != e->src->h) { fail("DecodeImageFailed", "unexpected frame size"); goto done; }
-    av.RGBImageSetDefaults(&rgb, img);
-    rgb.depth = 8;                                        /* io.zig:470-471 */
-    rgb.format = img->alphaPlane ? AVIF_RGBA : AVIF_RGB;  /* io.zig:473 */
-    if (av.RGBImageAllocatePixels(&rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
-    if ((r = av.ImageYUVToRGB(img, &rgb)) != AVIF_OK) { fail("ConvertToRGBFailed", av.ResultToString(r)); goto done; }
-    double t2 = now_ms();
-    /* tq.zig:37, without the copy loop of io.zig:654-663: libavif's rows as they are */
-    r = ssimu2_score_against_reference_strided(scorer, rgb.pixels, rgb.rowBytes, rgb.format == AVIF_RGBA ? 4 : 3, out_score);
-    if (r != SSIMU2_OK) { fail("ScorerFailed", ssimu2_last_error(scorer)); goto done; }
-    times_ms[0] = t1 - t0; times_ms[1] = t2 - t1; times_ms[2] = now_ms() - t2;
+    av.RGBImageSetDefaults(&d->rgb, img);
+    d->rgb.depth = 8;                                        /* io.zig:470-471 */
+    d->rgb.format = img->alphaPlane ? AVIF_RGBA : AVIF_RGB;  /* io.zig:473 */
+    if (av.RGBImageAllocatePixels(&d->rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
+    if ((r = av.ImageYUVToRGB(img, &d->rgb)) != AVIF_OK) { fail("ConvertToRGBFailed", av.ResultToString(r)); goto done; }
+    times_ms[0] = t1 - t0; times_ms[1] = now_ms() - t1;
     *out_avif = avif; *out_size = avif_size;
     avif = NULL;
     rc = 0;
 done:
-    if (rgb.pixels) av.RGBImageFreePixels(&rgb);
-    if (dec) av.DecoderDestroy(dec);
+    if (rc) decoded_free(d);
     free(avif);
     return rc;
+}
+static int pass_score(ssimu2_ctx* scorer, Decoded* d, double* out_score, double times_ms[3]) {
+    /* tq.zig:37, without the copy loop of io.zig:654-663: libavif's rows as they are */
+    const double t = now_ms();
+    const int r = ssimu2_score_against_reference_strided(scorer, d->rgb.pixels, d->rgb.rowBytes,
+                                                         d->rgb.format == AVIF_RGBA ? 4 : 3, out_score);
+    times_ms[2] = now_ms() - t;
+    decoded_free(d);
+    return r == SSIMU2_OK ? 0 : fail("ScorerFailed", ssimu2_last_error(scorer));
+}
+
+static void phase(const char* what);
+static int ensure_scorer(EncCtx* e) { /* ssimu2_prefetch started this at process start; the first score waits for it */
+    if (e->scorer) return 0;
+    int rc = ssimu2_ctx_create(e->device, NULL, &e->scorer);
+    if (rc != SSIMU2_OK) return fail(rc == SSIMU2_ERR_NO_DEVICE ? "NoDevice" : "ScorerFailed", ssimu2_last_error(NULL));
+    phase("scorer context created");
+    if ((rc = ssimu2_ctx_set_blur(e->scorer, e->blur)) || (rc = ssimu2_set_reference(e->scorer, e->rgb8, e->src->w, e->src->h)))
+        return fail("ScorerFailed", ssimu2_last_error(e->scorer));
+    phase("reference uploaded and cached");
+    return 0;
 }
 
 static int probe(void* user, uint32_t q, double* out_score) { /* the sequential search's pass */
     EncCtx* e = (EncCtx*)user;
     uint8_t* avif = NULL;
     size_t n = 0;
-    double t[3];
-    if (pass_on(e, e->scorer, q, &avif, &n, out_score, t)) return -1;
+    double t[3] = {0, 0, 0};
+    Decoded d;
+    if (pass_cpu(e, q, &avif, &n, &d, t)) return -1;
+    if (e->scorer == NULL) phase("first probe encoded and decoded");
+    if (ensure_scorer(e) || pass_score(e->scorer, &d, out_score, t)) { decoded_free(&d); free(avif); return -1; }
     e->encode_ms += t[0]; e->decode_ms += t[1]; e->score_ms += t[2];
     free(e->buf); /* tq.zig:31-35: the buffer of this probe replaces the previous one */
     e->buf = avif; e->buf_size = n; e->buf_q = (int)q;
@@ -567,8 +595,10 @@ static void* spec_job(void* arg) {
     }
     uint8_t* avif = NULL;
     size_t n = 0;
-    double t[3];
-    if (pass_on(s->e, s->ctx[j->slot], j->q, &avif, &n, &j->score, t)) return NULL;
+    double t[3] = {0, 0, 0};
+    Decoded d;
+    if (pass_cpu(s->e, j->q, &avif, &n, &d, t)) return NULL;
+    if (pass_score(s->ctx[j->slot], &d, &j->score, t)) { free(avif); return NULL; }
     pthread_mutex_lock(&g_lock);
     s->e->encode_ms += t[0]; s->e->decode_ms += t[1]; s->e->score_ms += t[2];
     if (s->nkept < (int)(sizeof s->kept / sizeof s->kept[0])) {
@@ -721,28 +751,27 @@ static int run_inner(Run* r, int argc, char** argv) {
         fprintf(stderr, "Searching [tgt %.0f±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
     else
         fprintf(stderr, "Searching [tgt %g±%.1f, speed %d, %u-bit]\n", o.score_tgt, o.tolerance, o.speed, out_depth);
-    if (make_source_image(e)) return -1; /* the CPU side of the first pass's set-up overlaps the scorer's start-up */
-    phase("source converted to YUV444");
-    int rc = ssimu2_ctx_create(device, NULL, &e->scorer);
-    if (rc != SSIMU2_OK) return fail(rc == SSIMU2_ERR_NO_DEVICE ? "NoDevice" : "ScorerFailed", ssimu2_last_error(NULL));
-    phase("scorer context created");
     /* the blur of the search path: the published recursion unless OAVIF_SSIMU2_BLUR says otherwise (as the
        Zig shim's `blur` and the Python mirror: INTEGRATION.md section 2e) */
     const char* bm = getenv("OAVIF_SSIMU2_BLUR");
     int mode = SSIMU2_BLUR_RECURSIVE;
     if (bm && !strcmp(bm, "fir")) mode = SSIMU2_BLUR_FIR;
     else if (bm && (!strcmp(bm, "recursive_fma") || !strcmp(bm, "iir_fma"))) mode = SSIMU2_BLUR_RECURSIVE_FMA;
-    if ((rc = ssimu2_ctx_set_blur(e->scorer, mode)) || (rc = ssimu2_set_reference(e->scorer, r->rgb8, src->w, src->h)))
-        return fail("ScorerFailed", ssimu2_last_error(e->scorer));
-    phase("reference uploaded and cached");
+    e->device = device; e->blur = mode; e->rgb8 = r->rgb8;
+    int rc;
+    if (make_source_image(e)) return -1;
+    phase("source converted to YUV444");
+    /* The scorer context is NOT created here: the HIP runtime started initialising in the background at process
+       start (ssimu2_prefetch) and takes 0.1-0.25 s; the CPU half of the first pass -- its quantizer does not
+       depend on any score (tq.zig:136) -- runs meanwhile, and the first score waits for whatever is left. */
     oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
     oavif_tq_result res;
     const int fan = getenv("OAVIF_PROBE_FANOUT") ? atoi(getenv("OAVIF_PROBE_FANOUT")) : 1;
     if (fan > 1) { /* not a CLI flag: the option surface stays the reference's (parse_args.zig:76-122) */
-        if (make_source_image(e)) return -1; /* before the first wave: the threads only read it */
-        Spec* sp = &r->spec;
+        Spec* sp = &r->spec; /* the source image exists before the first wave: the threads only read it */
         sp->e = e; sp->rgb8 = r->rgb8; sp->blur = mode;
         sp->fan = fan > OAVIF_TQ_MAX_FANOUT ? OAVIF_TQ_MAX_FANOUT : (uint32_t)fan;
+        if (ensure_scorer(e)) return -1; /* the fan-out needs its contexts up front */
         sp->ctx[0] = e->scorer;
         sp->have_ref[0] = 1;
         for (uint32_t i = 1; i < sp->fan; ++i) /* contexts are made here, on one thread; each is one HIP stream + scratch */
@@ -792,9 +821,16 @@ static int run(int argc, char** argv) {
 
 int main(int argc, char** argv) {
     fprintf(stderr, "\x1b[31moavif\x1b[0m | %s\n", VERSION);
+    int rc = 0;
     if (run(argc, argv)) {
         fprintf(stderr, "error: %s%s%s\n", g_err ? g_err : "Unexpected", g_detail[0] ? ": " : "", g_detail);
-        return 1;
+        rc = 1;
     }
-    return 0;
+    /* Everything this process owns is released and its output is on disk.  The HIP runtime's exit handlers then
+       spend another 50-100 ms unloading code objects and tearing the device context down -- a third of a 1080p
+       run -- for memory the kernel reclaims anyway: leave without them (OAVIF_HOST_ATEXIT=1 keeps them, for
+       leak checkers). */
+    fflush(NULL);
+    if (!getenv("OAVIF_HOST_ATEXIT")) _exit(rc);
+    return rc;
 }
