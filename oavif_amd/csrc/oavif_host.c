@@ -766,6 +766,8 @@ static int run_inner(Run* r, int argc, char** argv) {
        depend on any score (tq.zig:136) -- runs meanwhile, and the first score waits for whatever is left. */
     oavif_tq_options to = {o.score_tgt, o.tolerance, (uint32_t)o.max_pass};
     oavif_tq_result res;
+    int spec_used = 0;
+    oavif_tq_spec_stats spec_stats = {0, 0, 0};
     const int fan = getenv("OAVIF_PROBE_FANOUT") ? atoi(getenv("OAVIF_PROBE_FANOUT")) : 1;
     if (fan > 1) { /* not a CLI flag: the option surface stays the reference's (parse_args.zig:76-122) */
         Spec* sp = &r->spec; /* the source image exists before the first wave: the threads only read it */
@@ -785,8 +787,7 @@ static int run_inner(Run* r, int argc, char** argv) {
                 e->buf = sp->kept[k].b; e->buf_size = sp->kept[k].n; e->buf_q = sp->kept[k].q;
                 sp->kept[k].b = NULL;
             }
-        if (getenv("OAVIF_HOST_TIMES"))
-            fprintf(stderr, "speculative: %u waves, %u probes issued, %u cache hits\n", st.waves, st.probes_issued, st.cache_hits);
+        spec_used = 1; spec_stats = st;
     } else {
         rc = oavif_tq_find_target_quality(&to, probe, e, &res);
         if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
@@ -802,6 +803,9 @@ static int run_inner(Run* r, int argc, char** argv) {
     }
     fprintf(stderr, "Compressed to %zu bytes (%.3f bpp)\n", e->buf_size, e->buf_size * 8.0 / (double)px);
     if (depth_note) fprintf(stderr, "%s\n", depth_note);
+    if (getenv("OAVIF_HOST_TIMES") && spec_used)
+        fprintf(stderr, "speculative: %u waves, %u probes issued, %u cache hits\n", spec_stats.waves,
+                spec_stats.probes_issued, spec_stats.cache_hits);
     if (getenv("OAVIF_HOST_TIMES")) /* not one of the reference's lines: only on request */
         fprintf(stderr, "times: encode %.1f ms, decode %.1f ms, upload+score %.2f ms over %u passes\n", e->encode_ms,
                 e->decode_ms, e->score_ms, res.num_pass);
