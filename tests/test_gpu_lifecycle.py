@@ -36,6 +36,10 @@ def test_contexts_give_their_device_memory_back(hip_lib):
         rec_alive = base - _free()
         s.set_blur(_lib.BLUR_FIR)                                  # frees the recursive modes' planes
         back_to_fir = base - _free()
+        with pytest.raises(oavif_amd.scorer.Ssimu2Error) as err:   # "a cached reference is dropped" (ssimu2_hip.h)
+            s.score_against_reference(d_big)
+        assert err.value.code == -5 if hasattr(err.value, "code") else "no reference" in str(err.value)
+        s.set_reference(big)
         assert s.score_against_reference(d_big) == s.compute_ssimu2(big, d_big) == b
         s.close()
         after = base - _free()
