@@ -196,3 +196,49 @@ def test_host_is_clean_under_sanitizers(tmp_path, hip_lib):
                                     OAVIF_HOST_ATEXIT="1"))      # leave through exit(): LeakSanitizer reports there
         assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stderr[-3000:])
         assert r.returncode == want, (args, r.stderr[-800:])
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_search_path_of_the_host_under_sanitizers_with_a_stub_scorer(tmp_path, san):
+    """The host's whole search path on the CPU: oavif_host.c + the real search code (tq.cpp) + the real PNG ingest
+    + the real libavif, with tests/c/stub_scorer.c standing in for the GPU scorer (test infrastructure: a monotone
+    stand-in score).  ASan + UBSan + LSan, and TSan for the pthread fan-out of the speculative search
+    (OAVIF_PROBE_FANOUT): no report, and the fanned search prints and writes what the sequential one does."""
+    import shutil
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("gcc / g++ missing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "oavif_amd", "csrc")
+    inc = os.path.join(root, "include")
+    flags = ["-O1", "-g", f"-fsanitize={san}", "-fno-omit-frame-pointer", "-I", inc]
+    objs = []
+    for src, cc, std in (("oavif_host.c", "gcc", "-std=gnu11"), ("tq.cpp", "g++", "-std=c++17"),
+                         ("png_ingest.cpp", "g++", "-std=c++17"),
+                         (os.path.join(root, "tests", "c", "stub_scorer.c"), "gcc", "-std=gnu11")):
+        path = src if os.path.isabs(src) else os.path.join(csrc, src)
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.run([cc, std, *flags, "-c", path, "-o", obj], check=True, capture_output=True)
+        objs.append(obj)
+    exe = str(tmp_path / "host_stub")
+    subprocess.run(["g++", f"-fsanitize={san}", *objs, "-o", exe, "-ldl", "-lm", "-lz", "-lpthread"], check=True,
+                   capture_output=True)
+    _ref, png, p = _inputs(tmp_path, 160, 120, seed=5)
+    env = dict(ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", TSAN_OPTIONS="halt_on_error=1",
+               OAVIF_HOST_ATEXIT="1", OAVIF_HOST_TIMES="1")
+    outs = {}
+    for src, args in ((png, ["--score-tgt", "91", "--tolerance", "1", "--max-pass", "8", "--tenbit", "0", "-s", "10"]),
+                      (p, ["-t", "85", "--tolerance", "1", "--tenbit", "0", "-s", "10", "--quality-alpha", "60"])):
+        for fan in ("1", "4", "16"):
+            out = tmp_path / f"o_{src.suffix[1:]}_{fan}.avif"
+            r = subprocess.run([exe, *args, str(src), str(out)], capture_output=True, text=True, timeout=600,
+                               env=_env(OAVIF_PROBE_FANOUT=fan, **env))
+            assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (fan, r.stderr[-3000:])
+            assert r.returncode == 0, r.stderr[-1500:]
+            lines = [l for l in r.stderr.splitlines() if not l.startswith("  [")]
+            found = [l for l in lines if l.startswith("Found q")]
+            assert len(found) == 1
+            outs[(src, fan)] = (found[0], [l for l in lines if l.startswith("Compressed to")], out.read_bytes())
+            if fan != "1":
+                assert any(l.startswith("speculative: ") for l in lines)
+        assert outs[(src, "1")] == outs[(src, "4")] == outs[(src, "16")]
+        assert int(re.search(r"(\d+) passes", outs[(src, "1")][0]).group(1)) >= 2      # a real multi-pass search
