@@ -6,6 +6,7 @@ library that is present, that its struct-layout guard works, and what that libra
 Pillow's own plugin -- another binding of the same libavif -- is the independent cross-check of the pixels.
 No GPU."""
 import io
+import os
 import threading
 
 import numpy as np
@@ -278,3 +279,19 @@ def test_encoder_source_hoists_the_yuv_conversion_without_changing_a_byte():
     assert cli._encode(None, _opts(tenbit=False), 50, icc=None, prepared=prepared) == \
         ab.encode(np.repeat(rgba[..., :1], 3, axis=2), 8, _opts(tenbit=False), 50)
     prepared.close()
+
+
+def test_a_missing_or_foreign_library_turns_the_bridge_off_with_a_reason(tmp_path):
+    """OAVIF_LIBAVIF names the library; one that cannot be opened, or that is not libavif, leaves available()
+    False with the reason, and the CLI mirror then encodes through Pillow's plugin and says so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from oavif_amd import avif_bridge as ab, cli; print(ab.available()); print(ab.why_unavailable()); "
+            "print(cli.codec_depth(True, False)[1])")
+    for lib, needle in (("/nonexistent/libavif.so", "cannot open shared object"), ("libz.so.1", "undefined symbol")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
+                           env=dict(os.environ, OAVIF_LIBAVIF=lib, PYTHONPATH=root))
+        out = r.stdout.splitlines()
+        assert r.returncode == 0 and out[0] == "False", r.stderr
+        assert needle in out[1] and "bridge is off" in out[2], out
