@@ -63,6 +63,33 @@ def test_bypass_writes_the_python_mirrors_bytes(host, tmp_path, capsys):
         assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
 
 
+def test_16_bit_palette_and_icc_sources_go_the_mirrors_way(host, tmp_path, capsys):
+    """io.loadPNG's output rules through the C ABI's loader in both hosts: a 16-bit RGB PNG (hbd: RGBA16 to the
+    encoder after `>> 8`, or `>> 6` where 10-bit can be written; `>> 8` for the scorer, io.zig:63-95,587,602), a
+    palette PNG (RGBA8) and an ICC profile handed on to the AVIF (io.zig:556-560): same stderr lines, same bytes."""
+    import io as _io
+    from PIL import Image, ImageCms
+    from tests.test_png import write_png
+    rng = np.random.default_rng(5)
+    ref = synth.make_ref(96, 64, 9)
+    deep = (ref.astype(np.uint16) << 8) | rng.integers(0, 256, ref.shape, dtype=np.uint16)
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+    (tmp_path / "deep.png").write_bytes(write_png(deep, 2, 16, icc=icc))
+    idx = (ref[..., :1] >> 4).astype(np.uint8)
+    plte = np.stack([np.arange(16) * 17, 255 - np.arange(16) * 17, (np.arange(16) * 40) % 256], axis=1)
+    (tmp_path / "pal.png").write_bytes(write_png(idx, 3, 4, plte=plte))
+    for name, read_line in (("deep.png", "Read 96x64, RGBA, 16-bit, "), ("pal.png", "Read 96x64, RGBA, 8-bit, ")):
+        r = _run(host, ["-q", "70", str(tmp_path / name), str(tmp_path / "c.avif")])
+        assert r.returncode == 0, r.stderr
+        assert cli.main(["-q", "70", str(tmp_path / name), str(tmp_path / "p.avif")]) == 0
+        perr = capsys.readouterr().err.splitlines()
+        cerr = r.stderr.splitlines()
+        assert cerr[1].startswith(read_line) and cerr[1:4] == perr[1:4], (cerr, perr)
+        assert (tmp_path / "c.avif").read_bytes() == (tmp_path / "p.avif").read_bytes()
+    r = _run(host, ["-q", "70", str(tmp_path / "deep.png"), str(tmp_path / "d.avif")])
+    assert Image.open(_io.BytesIO((tmp_path / "d.avif").read_bytes())).info.get("icc_profile") == icc
+
+
 def test_default_depth_is_reported_like_the_mirror(host, tmp_path):
     _ref, png, _p = _inputs(tmp_path)
     r = _run(host, ["-q", "50", str(png), str(tmp_path / "c.avif")])     # --tenbit 1 is the default
