@@ -354,7 +354,7 @@ class EncoderSource:
             L.avifEncoderDestroy(enc)
 
     def close(self) -> None:
-        if self._image is not None:
+        if getattr(self, "_image", None) is not None:
             self._L.avifImageDestroy(self._image)
             self._image = None
 
@@ -396,7 +396,7 @@ class DecodedFrame:
         return np.array(a[..., :3], order="C", copy=True)   # a copy: `rows` dies with close()
 
     def close(self) -> None:
-        if self._rgb is not None:
+        if getattr(self, "_rgb", None) is not None:
             self.rows = None
             self._L.avifRGBImageFreePixels(self._rgb)
             self._L.avifDecoderDestroy(self._dec)
