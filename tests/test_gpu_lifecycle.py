@@ -9,6 +9,7 @@ from oavif_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
 MB = 1 << 20
+SLACK = 32 * MB   # the runtime's own pools may move by a few MB; one leaked 1080p plane set is 230 MB, a leaked FIR context 60
 
 
 def _free():
@@ -21,8 +22,12 @@ def test_contexts_give_their_device_memory_back(hip_lib):
     small = synth.make_ref(640, 360, 1)
     big = synth.make_ref(1920, 1080, 2)
     d_small, d_big = synth.distort(small, "blockq", 2), synth.distort(big, "noise", 2)
-    with oavif_amd.Ssimu2(0) as warm:      # the process-wide pieces (code object, stream pool) exist before the baseline
-        warm.compute_ssimu2(small, d_small)
+    with oavif_amd.Ssimu2(0) as warm:      # the process-wide pieces (code object, stream pool, the runtime's own
+        warm.compute_ssimu2(small, d_small)   # pools for every kernel of both modes) exist before the baseline
+        warm.compute_ssimu2(big, d_big)
+        warm.set_blur(_lib.BLUR_RECURSIVE)
+        warm.set_reference(big)
+        warm.score_against_reference(d_big)
     base = _free()
     want = None
     for cycle in range(12):
@@ -48,8 +53,8 @@ def test_contexts_give_their_device_memory_back(hip_lib):
         assert (a, b, c) == want                                   # and the scores never move
         # 1080p: the recursive modes hold 21 padded planes x 1.333 scales = ~0.23 GB on top of the FIR buffers
         assert 150 * MB < rec_alive - fir_alive < 330 * MB, (fir_alive / MB, rec_alive / MB)
-        assert abs(back_to_fir - fir_alive) <= 8 * MB, (back_to_fir / MB, fir_alive / MB)
-        assert abs(after) <= 8 * MB, f"cycle {cycle}: {after / MB:.1f} MB not returned"
+        assert abs(back_to_fir - fir_alive) <= SLACK, (back_to_fir / MB, fir_alive / MB)
+        assert abs(after) <= SLACK, f"cycle {cycle}: {after / MB:.1f} MB not returned"
 
 
 def test_many_contexts_at_once_and_out_of_order_destruction(hip_lib):
@@ -66,4 +71,4 @@ def test_many_contexts_at_once_and_out_of_order_destruction(hip_lib):
     assert len(set(got[1::2])) == 1 and abs(got[1] - want) < 0.5   # recursive contexts agree among themselves
     for i in (5, 0, 15, 7, 8, 1, 2, 14, 3, 13, 4, 12, 6, 11, 9, 10):
         ctxs[i].close()
-    assert abs(base - _free()) <= 8 * MB
+    assert abs(base - _free()) <= SLACK
