@@ -3,7 +3,9 @@ response vs the published recursion itself) as a function of frame size, on real
 the recursion's rounding noise averages out over more pixels, so the modes agree better on large
 frames.  Prints per size the median / 95th percentile / max |score_FIR - score_recursive| and how
 often a target-quality search ends on the same quantizer in both modes.
-Usage: gpu_blur_mode_gap.py [IMAGES_PER_SIZE] [--only WxH] [--json PATH]
+Usage: gpu_blur_mode_gap.py [IMAGES_PER_SIZE] [--only WxH] [--json PATH] [--bridge]
+--bridge: the probes come from libavif's C API under the reference's calls and defaults (oavif_amd.avif_bridge: tune=iq,
+one encoder thread, 8-bit here) instead of Pillow's plugin.
 --json writes one record per search (seed, target, the quantizer and score each mode ends on, passes) -- the
 4K record of round 4 is profiles/r04_4k_search_both_modes.json (24 searches: 6 images x 4 targets)."""
 import os, sys, time
@@ -16,6 +18,13 @@ from oavif_amd import synth, tq
 import json
 argv = sys.argv[1:]
 json_path = only = None
+bridge = "--bridge" in argv
+if bridge:
+    argv.remove("--bridge")
+    from oavif_amd import avif_bridge as ab, cli
+    assert ab.available(), ab.why_unavailable()
+    enc_o = cli.AvifEncOptions()
+    enc_o.tenbit = False
 if "--json" in argv:
     json_path = argv[argv.index("--json") + 1]
     del argv[argv.index("--json"):argv.index("--json") + 2]
@@ -39,10 +48,15 @@ for (w, h) in sizes:
         if i % 3 == 1:
             ref = np.clip(ref.astype(np.int16) + rng.integers(-12, 13, ref.shape), 0, 255).astype(np.uint8)
         cache = {}
+        src_img = ab.EncoderSource(ref, 8, enc_o) if bridge else None
 
         def codec(q):
             if q not in cache:
-                cache[q] = synth.avif_roundtrip(ref, q, speed=9)
+                if bridge:
+                    data = src_img.encode(enc_o, q)
+                    cache[q] = (ab.decode_rgb8(data), len(data))
+                else:
+                    cache[q] = synth.avif_roundtrip(ref, q, speed=9)
             return cache[q]
         for tgt in targets:
             a = tq.search_hip(fir, ref, codec, score_tgt=tgt)
@@ -67,7 +81,9 @@ for (w, h) in sizes:
           f"(largest |dq| {max(dq)})  [{time.time() - t0:.0f}s]", flush=True)
 if json_path:
     nsame = sum(r["q_fir"] == r["q_recursive"] for r in records)
-    json.dump({"what": "target-quality searches (tq.zig:124-210 restated, real AVIF probes through Pillow's libavif/aom speed 9) "
+    json.dump({"what": "target-quality searches (tq.zig:124-210 restated, real AVIF probes through " +
+                       ("libavif's C API with the reference's calls and defaults: YUV444, tune=iq, speed 9, one thread, 8-bit) " if bridge
+                        else "Pillow's libavif/aom speed 9) ") +
                        "driven by the HIP scorer in each blur mode; which mode fssimu2 0.1.1 follows is unknown (parity unpinned)",
                "searches": len(records), "same_quantizer_fir_vs_recursive": nsame,
                "same_quantizer_recursive_vs_recursive_fma": sum(r["q_recursive"] == r["q_recursive_fma"] for r in records),
