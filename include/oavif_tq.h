@@ -168,7 +168,7 @@ void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v
  * without an alpha channel come out opaque (this reading of libspng is unpinned: libspng is not in
  * the image and the reference holds no PNG fixture).  These two functions are that loader without
  * libspng: the PNG specification over zlib (chunk CRCs, the five row filters, Adam7, PLTE / iCCP),
- * inflated scanline by scanline (two rows of memory, whatever the header claims).  A header that
+ * inflated strip by strip (256 KB or one row of memory, whatever the header claims).  A header that
  * promises more scanline bytes than its IDAT data can inflate to (deflate's 1032 : 1 bound) fails
  * with OAVIF_PNG_ERR_DECODE in both calls.  Host code; no GPU involved.
  *

@@ -168,6 +168,25 @@ def test_every_colour_type_depth_filter_and_adam7(hip_lib, ctype, depth, interla
         assert (info.width, info.height, info.bit_depth, info.color_type, info.interlaced) == (w, h, depth, ctype, int(interlace))
 
 
+@pytest.mark.parametrize("ctype,depth", [(2, 8), (6, 8), (4, 16), (2, 16), (0, 8)])   # 3-, 4-, 4-, 6- and 1-byte pixels
+@pytest.mark.parametrize("ftype", [1, 2, 3, 4])
+def test_each_filter_on_every_row_and_strips_of_rows(hip_lib, ctype, depth, ftype):
+    """Every row of the file under ONE filter type (the vector forms of Sub / Average / Paeth for 3- and 4-byte
+    pixels, the byte-wise forms for the rest), smooth and noisy content, widths around the vector step, and
+    images taller than one inflate strip (256 KB) so that the row above a strip's first row is carried over."""
+    rng = np.random.default_rng(1000 + ctype * 10 + ftype + depth)
+    hi = 1 << depth
+    for (w, h) in ((1, 3), (2, 2), (3, 7), (31, 4), (257, 5), (640, 300)):
+        noise = rng.integers(0, hi, (h, w, NSAMP[ctype]))
+        ramp = ((np.arange(w)[None, :, None] * 3 + np.arange(h)[:, None, None] * 5 + np.arange(NSAMP[ctype])[None, None, :] * 40)
+                * (hi // 256)) % hi
+        for smp in (noise, ramp, np.where(noise > hi // 2, hi - 1, 0)):     # random, smooth, extremes (ties of Paeth)
+            data = write_png(smp, ctype, depth, filters=(ftype,))
+            exp, ch, hbd = expected(smp, ctype, depth)
+            pix, c, hb, _icc = png.load_png(data)
+            assert (c, hb) == (ch, hbd) and np.array_equal(pix, exp), (ctype, depth, ftype, w, h)
+
+
 def test_icc_profile_is_handed_on_decompressed(hip_lib):
     smp = np.arange(4 * 5 * 3).reshape(5, 4, 3) % 256
     profile = bytes(range(256)) * 5
