@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/oavif_tq.h"
+#include "inflate_fast.h"
 
 namespace {
 
@@ -406,89 +407,104 @@ int oavif_png_decode(const uint8_t* png_bytes, size_t len, uint8_t* out_pixels, 
         if (out_cap < info.data_bytes || (info.icc_bytes && out_icc && icc_cap < info.icc_bytes)) return OAVIF_PNG_ERR_SIZE;
         if (info.hbd && (reinterpret_cast<uintptr_t>(out_pixels) & 1u)) return OAVIF_PNG_ERR_ARG;  // u16 output
         if (out_icc && info.icc_bytes) memcpy(out_icc, icc.data(), icc.size());
-        // Inflate a STRIP of scanlines at a time (at most kStripBytes, at least one row), unfilter each against
-        // the row above and expand it into the caller's pixels: memory is one strip + one row whatever the header
-        // claims, and a stream that ends early fails at the strip where it ends (libspng's progressive decode
-        // fails at the row).  One inflate() call per row -- round 3's form -- made zlib copy every row through its
-        // window a second time; whole strips inflate at the speed of a one-shot decompress.
+        // The IDAT stream is inflated by inflate_fast.h (1.5-1.75 x zlib on PNG streams) into a sliding buffer:
+        // 32 KB of history + a strip of at most kStripBytes (at least one row).  Each filtered scanline is copied
+        // out of it -- for 8-bit RGB / RGBA straight into the caller's pixels, else into a row buffer --,
+        // unfiltered against the row above and expanded: memory is the compressed stream + one strip + two rows
+        // whatever the header claims, and a stream that ends early fails where it ends.  (Matches copy from the
+        // FILTERED bytes, so rows are never unfiltered inside the window.)
         const Geometry geo = geometry(png);
         size_t max_rb = 0;
         for (int k = 0; k < geo.npass; ++k)
             if (geo.pw[k] && geo.ph[k]) max_rb = row_bytes(png, geo.pw[k]) > max_rb ? row_bytes(png, geo.pw[k]) : max_rb;
+        size_t zbytes = 0;
+        for (const auto& c : png.idat) zbytes += c.n;
+        if (zbytes < 2) return OAVIF_PNG_ERR_DECODE;
+        std::vector<uint8_t> z(zbytes + finf::kPad, 0);
+        {
+            size_t at = 0;
+            for (const auto& c : png.idat) {
+                memcpy(z.data() + at, c.p, c.n);
+                at += c.n;
+            }
+        }
+        // zlib wrapper (RFC 1950): deflate, window <= 32 KB, header check, no preset dictionary.  The Adler-32
+        // behind the stream is not read: decoding stops at the last scanline, as it always did here.
+        if ((z[0] & 0x0f) != 8 || (z[0] >> 4) > 7 || ((z[0] << 8) | z[1]) % 31 != 0 || (z[1] & 0x20)) return OAVIF_PNG_ERR_DECODE;
         constexpr size_t kStripBytes = 256 * 1024;
         const size_t strip_cap = (max_rb + 1) > kStripBytes ? (max_rb + 1) : kStripBytes;
-        std::vector<uint8_t> strip(strip_cap), above(max_rb + 1);
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit(&zs) != Z_OK) return OAVIF_PNG_ERR_OOM;
-        size_t chunk = 0;
-        bool stream_end = false;
-        zs.next_in = const_cast<uint8_t*>(png.idat[0].p);
-        zs.avail_in = (uInt)png.idat[0].n;
-        // fill dst[0..n) from the zlib stream that runs through the IDAT chunks; false = it ended or broke first
-        auto read_bytes = [&](uint8_t* dst, size_t n) -> bool {
-            zs.next_out = dst;
-            size_t left = n;
-            while (left) {
-                if (stream_end) return false;
-                if (zs.avail_in == 0) {
-                    if (++chunk >= png.idat.size()) return false;  // truncated
-                    zs.next_in = const_cast<uint8_t*>(png.idat[chunk].p);
-                    zs.avail_in = (uInt)png.idat[chunk].n;
-                    continue;
+        std::vector<uint8_t> win(finf::kWindow + strip_cap + (max_rb + 1) + finf::kOutMargin);
+        std::vector<uint8_t> rowbuf(2 * (max_rb + 1));
+        static thread_local finf::Stream zs;  // 13 KB of tables: not on the stack of a worker thread
+        zs.init(z.data() + 2, zbytes - 2);
+        size_t have = 0;     // valid bytes at the start of `win`
+        size_t row_pos = 0;  // offset in `win` of the next filtered scanline that has not been taken
+        bool ended = false;
+        // make at least n bytes available at win[row_pos..]; false = the stream ended or broke first
+        auto need = [&](size_t n) -> bool {
+            while (have - row_pos < n) {
+                if (ended) return false;
+                // slide: keep the history a match may reach (kWindow) and everything not yet taken
+                const size_t keep_from = row_pos < (have > finf::kWindow ? have - finf::kWindow : 0)
+                                             ? row_pos : (have > finf::kWindow ? have - finf::kWindow : 0);
+                if (keep_from) {
+                    memmove(win.data(), win.data() + keep_from, have - keep_from);
+                    have -= keep_from;
+                    row_pos -= keep_from;
                 }
-                zs.avail_out = (uInt)(left > 0x40000000u ? 0x40000000u : left);
-                const size_t before = zs.avail_out;
-                const int zrc = inflate(&zs, Z_NO_FLUSH);
-                left -= before - zs.avail_out;
-                if (zrc == Z_STREAM_END) stream_end = true;
-                else if (zrc != Z_OK && !(zrc == Z_BUF_ERROR && zs.avail_in == 0)) return false;
+                uint8_t* o = win.data() + have;
+                const finf::Result r = finf::run(zs, win.data(), o, win.data() + win.size());
+                const size_t got = (size_t)(o - (win.data() + have));
+                have += got;
+                if (r == finf::kError) return false;
+                if (r == finf::kDone) ended = true;
+                else if (got == 0) return false;  // no progress with room to spare: cannot happen; do not spin
             }
             return true;
         };
         const size_t bpp = (size_t)(png.bits_per_pixel() + 7) / 8;
         const Expander ex{png, out_pixels};
         int result = OAVIF_PNG_OK;
+        const bool direct = !png.interlace && png.depth == 8 && (png.ctype == 2 || png.ctype == 6);  // rows go out as they are
         for (int k = 0; k < geo.npass && result == OAVIF_PNG_OK; ++k) {
             if (!geo.pw[k] || !geo.ph[k]) continue;
             const size_t rb = row_bytes(png, geo.pw[k]);
-            const size_t rows_per_strip = strip_cap / (rb + 1);  // >= 1
-            const uint8_t* prev = above.data();
-            memset(above.data(), 0, rb);  // a pass's first row has zeros above it
+            uint8_t* cur = rowbuf.data();
+            uint8_t* above = rowbuf.data() + max_rb + 1;
+            memset(above, 0, rb);  // a pass's first row has zeros above it
+            const uint8_t* prev = above;
             const Pass a = png.interlace ? kAdam7[k] : Pass{0, 0, 1, 1};
-            for (uint32_t j0 = 0; j0 < geo.ph[k] && result == OAVIF_PNG_OK; j0 += (uint32_t)rows_per_strip) {
-                const uint32_t nrows = geo.ph[k] - j0 < rows_per_strip ? geo.ph[k] - j0 : (uint32_t)rows_per_strip;
-                if (!read_bytes(strip.data(), (size_t)nrows * (rb + 1))) {
+            for (uint32_t j = 0; j < geo.ph[k]; ++j) {
+                if (!need(rb + 1)) {
                     result = OAVIF_PNG_ERR_DECODE;
                     break;
                 }
-                for (uint32_t r = 0; r < nrows; ++r) {
-                    uint8_t* cur = strip.data() + (size_t)r * (rb + 1);
-                    if (unfilter(cur[0], cur + 1, prev, rb, bpp)) {
-                        result = OAVIF_PNG_ERR_DECODE;
-                        break;
-                    }
-                    const uint8_t* row = cur + 1;
-                    prev = row;
-                    const uint32_t y = a.y0 + (j0 + r) * a.dy;
-                    if (!png.interlace && png.depth == 8 && (png.ctype == 2 || png.ctype == 6)) {
-                        memcpy(out_pixels + (size_t)y * rb, row, rb);  // RGB8 / RGBA8 rows go out as they are
-                    } else {
-                        for (uint32_t i = 0; i < geo.pw[k]; ++i)
-                            if (!ex.put(row, i, a.x0 + i * a.dx, y)) {
-                                result = OAVIF_PNG_ERR_DECODE;
-                                break;
-                            }
-                        if (result != OAVIF_PNG_OK) break;
-                    }
+                const uint8_t* frow = win.data() + row_pos;
+                row_pos += rb + 1;
+                const uint32_t y = a.y0 + j * a.dy;
+                uint8_t* dst = direct ? out_pixels + (size_t)y * rb : cur;
+                memcpy(dst, frow + 1, rb);
+                if (unfilter(frow[0], dst, prev, rb, bpp)) {
+                    result = OAVIF_PNG_ERR_DECODE;
+                    break;
                 }
-                if (result == OAVIF_PNG_OK) {  // the strip's last row is the row above the next strip's first
-                    memcpy(above.data(), prev, rb);
-                    prev = above.data();
+                prev = dst;
+                if (!direct) {
+                    for (uint32_t i = 0; i < geo.pw[k]; ++i)
+                        if (!ex.put(dst, i, a.x0 + i * a.dx, y)) {
+                            result = OAVIF_PNG_ERR_DECODE;
+                            break;
+                        }
+                    if (result != OAVIF_PNG_OK) break;
+                    uint8_t* t = cur;  // the row just made is the row above the next one
+                    cur = above;
+                    above = t;
                 }
             }
         }
-        inflateEnd(&zs);  // data behind the last scanline is ignored
+        // data behind the last scanline is ignored; a stream that only "decoded" because the padding behind the
+        // input reads as zeros is a truncated one
+        if (result == OAVIF_PNG_OK && zs.overrun()) result = OAVIF_PNG_ERR_DECODE;
         if (result != OAVIF_PNG_OK) return result;
     } catch (const std::bad_alloc&) {
         return OAVIF_PNG_ERR_OOM;

@@ -31,6 +31,8 @@ static uint32_t rnd_state = 12345u;
 static uint32_t rnd() { return rnd_state = rnd_state * 1664525u + 1013904223u; }
 
 static Bytes make_png(uint32_t w, uint32_t h, int ctype, int depth, int interlace) {
+    static int made = 0;
+    const bool low_entropy = (made++ & 1) != 0;
     const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
     Bytes png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A}, d;
     put32(d, w);
@@ -58,12 +60,14 @@ static Bytes make_png(uint32_t w, uint32_t h, int ctype, int depth, int interlac
         const size_t rb = ((size_t)pw * samples * depth + 7) / 8;
         for (uint32_t y = 0; y < ph; ++y) {
             raw.push_back((uint8_t)(f++ % 5));  // any filter type: the bytes are random anyway
-            for (size_t i = 0; i < rb; ++i) raw.push_back((uint8_t)(rnd() >> 11));
+            // every other file: few distinct bytes in runs, so that the deflate stream is made of matches (the
+            // match / window paths of the inflater), not of literals alone
+            for (size_t i = 0; i < rb; ++i) raw.push_back((uint8_t)(low_entropy ? ((rnd() >> 13) % 7 == 0 ? (rnd() >> 11) & 3 : (raw.empty() ? 0 : raw.back())) : rnd() >> 11));
         }
     }
     uLongf cap = compressBound((uLong)raw.size());
     Bytes comp(cap);
-    compress2(comp.data(), &cap, raw.data(), (uLong)raw.size(), 1);
+    compress2(comp.data(), &cap, raw.data(), (uLong)raw.size(), low_entropy ? 9 : 1);
     comp.resize(cap);
     chunk(png, "IDAT", comp);
     chunk(png, "IEND", Bytes());

@@ -56,3 +56,15 @@ def test_png_ingest_survives_corrupted_files_under_sanitizers(tmp_path):
                 "-I", INC, PNG, os.path.join(ROOT, "tests", "c", "png_sanitize.cpp"), "-o", exe, "-lz"],
                exe, ["300"])
     assert "png_sanitize ok" in out
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_fast_inflate_equals_zlib_and_survives_corruption_under_sanitizers(tmp_path):
+    """oavif_amd/csrc/inflate_fast.h (the DEFLATE decoder of the PNG ingest) against zlib itself: 1,250 valid
+    streams of every level / strategy / content decoded through output strips of awkward sizes must give the
+    source bytes; 10,000 corrupted or truncated streams must give an error or exactly zlib's bytes -- and zlib
+    must not accept anything this decoder refuses.  ASan + UBSan, no recovery."""
+    exe = str(tmp_path / "inflate_diff")
+    out = _run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                os.path.join(ROOT, "tests", "c", "inflate_diff.cpp"), "-o", exe, "-lz"], exe, ["250"])
+    assert "inflate_diff ok" in out
