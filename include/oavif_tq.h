@@ -167,8 +167,11 @@ void oavif_prescale_16_to_8(const uint16_t* src, size_t n, uint8_t* dst);   /* v
  * flags 0 (io.zig:285), i.e. without SPNG_DECODE_TRNS: a tRNS chunk is NOT applied and files
  * without an alpha channel come out opaque (this reading of libspng is unpinned: libspng is not in
  * the image and the reference holds no PNG fixture).  These two functions are that loader without
- * libspng: the PNG specification over zlib (chunk CRCs, the five row filters, Adam7, PLTE / iCCP),
- * inflated strip by strip (256 KB or one row of memory, whatever the header claims).  A header that
+ * libspng: the PNG specification (chunk CRCs, the five row filters -- Sub / Average / Paeth of 3- and 4-byte
+ * pixels in SSE2 --, Adam7, PLTE / iCCP) with zlib for the CRCs and the iCCP profile and the library's own
+ * resumable DEFLATE decoder for the IDAT stream (csrc/inflate_fast.h: 1.5-1.75 x zlib, checked against zlib
+ * stream for stream), inflated strip by strip (the compressed stream + 256 KB or one row of memory, whatever the
+ * header claims).  A header that
  * promises more scanline bytes than its IDAT data can inflate to (deflate's 1032 : 1 bound) fails
  * with OAVIF_PNG_ERR_DECODE in both calls.  Host code; no GPU involved.
  *
