@@ -310,3 +310,32 @@ def test_cli_loads_png_through_the_native_decoder(hip_lib, tmp_path, monkeypatch
     p2.write_bytes(write_png(g, 0, 2))
     s2 = cli.load_source(str(p2))
     assert not s2.hbd and s2.channels == 4 and np.array_equal(s2.rgb, np.repeat(g * 85, 3, 2).astype(np.uint8))
+
+
+def test_concurrent_decodes_do_not_share_state(hip_lib):
+    """The batch driver loads PNGs from 16 worker threads at once (ctypes drops the GIL); the inflater's tables
+    live in thread-local storage.  Eight threads, different files, many rounds: every decode equals the
+    single-threaded one."""
+    import threading
+    rng = np.random.default_rng(77)
+    files = []
+    for k in range(8):
+        w, h = 50 + 37 * k, 40 + 11 * k
+        ctype, depth = [(2, 8), (6, 8), (0, 8), (3, 8), (2, 16), (4, 8), (6, 16), (0, 4)][k]
+        hi = 1 << depth
+        plte = rng.integers(0, 256, (256, 3)) if ctype == 3 else None
+        smp = rng.integers(0, min(hi, 256) if ctype == 3 else hi, (h, w, NSAMP[ctype]))
+        if k % 2:
+            smp = (smp // (hi // 4 or 1)) * (hi // 4 or 1)      # few levels: long matches in the stream
+        files.append(write_png(smp, ctype, depth, interlace=bool(k & 1), plte=plte))
+    want = [png.load_png(f)[0] for f in files]
+    bad = []
+
+    def work(i):
+        for _ in range(25):
+            if not np.array_equal(png.load_png(files[i])[0], want[i]):
+                bad.append(i)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
