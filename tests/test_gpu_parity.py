@@ -47,6 +47,31 @@ def test_golden_fixtures(scorer, oracle, golden):
     assert abs(got - o["score_fir"]) <= TOL_SCORE
 
 
+def test_real_photographs_through_the_published_quality_ladder(hip_lib, scorer, oracle):
+    """Photographic content on the device: scikit-learn's two sample photographs through the JPEG ladder
+    SSIMULACRA2 was published with (tests/photo_ladder.py; tests/test_oracle.py holds the checker to the published
+    scores).  The HIP path in FIR mode equals the checker's FIR score and in the search path's default mode the
+    checker's recursion, to 1e-4, on every rung -- and so sits within 7 points of the published table itself."""
+    import oavif_amd
+    from oavif_amd import _lib
+    from tests.photo_ladder import LADDER, jpeg_round_trip, photographs
+    photos = photographs()
+    if not photos:
+        pytest.skip("scikit-learn's sample photographs are not installed")
+    with oavif_amd.Ssimu2(0, blur=_lib.BLUR_RECURSIVE) as rec:
+        for q, sub, published in LADDER:
+            got = []
+            for _name, ref in photos:
+                dist = jpeg_round_trip(ref, q, sub)
+                _check_pair(scorer, oracle, ref, dist)
+                r = rec.compute_ssimu2(ref, dist)
+                assert abs(r - oracle.compute_ssimu2(ref, dist, oracle.BLUR_IIR)) <= TOL_SCORE
+                rec.set_reference(ref)
+                assert rec.score_against_reference(dist) == r
+                got.append(r)
+            assert abs(float(np.mean(got)) - published) <= 7.0, (q, sub, published, got)
+
+
 def test_identical_is_exactly_100(scorer):
     ref = synth.make_ref(300, 200, 11)
     assert scorer.compute_ssimu2(ref, ref) == 100.0
