@@ -27,11 +27,26 @@ rng = np.random.default_rng(2026)
 sizes = [(384, 256), (320, 320), (500, 281), (257, 199), (640, 360)]
 targets = [55.0, 65.0, 75.0, 80.0, 85.0, 92.0]
 bad, worst, total_passes, t0 = [], 0.0, 0, time.time()
+# real photographs where the image has them (scikit-learn's two sample images and three crops / flips of each):
+# they take the place of the first synthetic images
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+photos = []
+try:
+    from photo_ladder import photographs
+    for _name, ph in photographs():
+        photos += [ph, np.ascontiguousarray(ph[:, ::-1]), np.ascontiguousarray(ph[40:340, 100:600]), np.ascontiguousarray(ph[::-1, 200:])]
+except Exception:  # noqa: BLE001
+    photos = []
+print(f"{len(photos)} of the {n_images} images are real photographs (scikit-learn's samples and crops of them)", flush=True)
 with oavif_amd.Ssimu2(0, blur=oavif_amd._lib.BLUR_RECURSIVE if recursive else None) as s:
     for i in range(n_images):
         w, h = sizes[i % len(sizes)]
-        ref = synth.make_ref(w, h, 7000 + i)
-        if i % 3 == 1:   # busier content
+        if i < len(photos):
+            ref = photos[i]
+            h, w = ref.shape[:2]
+        else:
+            ref = synth.make_ref(w, h, 7000 + i)
+        if i % 3 == 1 and i >= len(photos):   # busier content
             ref = np.clip(ref.astype(np.int16) + rng.integers(-12, 13, ref.shape), 0, 255).astype(np.uint8)
         cache = {}
 
