@@ -779,15 +779,15 @@ static int run_inner(Run* r, int argc, char** argv) {
         for (uint32_t i = 1; i < sp->fan; ++i) /* contexts are made here, on one thread; each is one HIP stream + scratch */
             if (ssimu2_ctx_create(device, NULL, &sp->ctx[i]) != SSIMU2_OK) return fail("ScorerFailed", ssimu2_last_error(NULL));
         oavif_tq_spec_options so = OAVIF_TQ_SPEC_OPTIONS_INIT(sp->fan, 1);
-        oavif_tq_spec_stats st;
-        rc = oavif_tq_find_target_quality_speculative(&to, &so, spec_batch, sp, &res, &st);
+        oavif_tq_spec_stats sst;
+        rc = oavif_tq_find_target_quality_speculative(&to, &so, spec_batch, sp, &res, &sst);
         if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
         for (int k = 0; k < sp->nkept; ++k)
             if (sp->kept[k].q == (int)res.q && !e->buf) { /* EncBuffer: here the bytes of the chosen q, if it was probed */
                 e->buf = sp->kept[k].b; e->buf_size = sp->kept[k].n; e->buf_q = sp->kept[k].q;
                 sp->kept[k].b = NULL;
             }
-        spec_used = 1; spec_stats = st;
+        spec_used = 1; spec_stats = sst;
     } else {
         rc = oavif_tq_find_target_quality(&to, probe, e, &res);
         if (rc) return g_err ? -1 : fail("SearchFailed", NULL);
