@@ -87,6 +87,46 @@ def load_counters(size):
     return c
 
 
+def recursive_kernel_rooflines(w: int, h: int, n_pad: int, live_pass_ms: float):
+    """Per-kernel achieved HBM rate of the recursive mode's cached pass at 3840x2160: algorithmic bytes (SURVEY 8d:
+    each stage reads its inputs once and writes its outputs once) over the kernel's average duration in the newest
+    profiles/rNN_rg_kernel_stats.csv (rocprofv3 --kernel-trace --stats over scripts/gpu_rg_bench.py)."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_rg_kernel_stats.csv")))
+    if not files or (w, h) != (3840, 2160):
+        return None
+    plane = n_pad * 4   # one fp32 plane over all scales, rows padded
+    want = {"k_pyramid_bands_xyb": ("positive-XYB planes of the decoded frame at every scale, from its bytes",
+                                    w * h * 3 + 3 * plane),
+            "k_rg_h<false, false>": ("horizontal recursion of {y, yy, xy} x 3 channels: reads the XYB planes of both "
+                                     "frames, writes nine planes", 6 * plane + 9 * plane),
+            "k_rg_v<false>": ("vertical recursion + maps: reads the nine planes, the six cached reference planes and "
+                              "the XYB planes of both frames", 21 * plane)}
+    rows = {}
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            for key in want:
+                if key in r["Name"] and (key != "k_rg_v<false>" or "emit" not in r["Name"]):
+                    rows[key] = float(r["AverageNs"]) * 1e-6
+    if len(rows) != len(want):
+        return None
+    ks = []
+    for key, (what, nbytes) in want.items():
+        ks.append({"kernel": key, "what": what, "ms": round(rows[key], 4), "algorithmic_bytes": int(nbytes),
+                   "achieved_GBps": round(nbytes / rows[key] / 1e6, 1), "frac_of_hbm_peak": round(nbytes / rows[key] / 1e6 / 8000.0, 3)})
+    return {"source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --kernel-trace --stats, committed with the round)",
+            "sum_of_kernels_ms": round(sum(rows.values()), 4), "live_ms_per_pass": round(live_pass_ms, 4), "peak_GBps": 8000.0,
+            "measured_stream_ceilings_GBps": {"read": 6000, "write": 5600, "mixed": 5100,
+                                              "source": "profiles/r04_rw_mix.txt"},
+            "kernels": ks,
+            "note": "all three are HBM-bound byte movers: the vertical pass reads at 0.95 of the measured read-stream "
+                    "ceiling, the horizontal pass and the conversion at 0.85 of the mixed one; what they move "
+                    "(1.75 GB per pass) is 4 x the strict minimum, the h -> v round trip of nine planes being the "
+                    "largest part (DESIGN.md section 4: why it stays)"}
+
+
 def cpu_baseline_child(argv) -> int:
     """bench.py --cpu-baseline-child CPUS THREADS W H SECONDS MAXREPS: the CPU checker (OpenMP build)
     timed on one core set in a process of its own -- the affinity is set before the first OpenMP region
@@ -594,6 +634,17 @@ def main() -> int:
                     "per stage, reference planes cached per search, v-pass fused with the maps and persistent "
                     "(one workgroup per CU); the default of the SEARCH path (shim, CLI, batch) since round 4, "
                     "`value` stays the FIR mode"}
+
+        # per-kernel rooflines of the recursive pass: the three launches of a reference-cached pass with their
+        # algorithmic bytes (planes as the kernels address them: rows padded to 128 floats) against the rocprofv3
+        # kernel-trace averages committed with the round (the same source the PMC traffic of `roofline` comes
+        # from: profiles/); the live whole-pass time above is the cross-check (it is their sum)
+        try:
+            rk = recursive_kernel_rooflines(w, h, n_pad, rc_ms)
+            if rk:
+                out["recursive_blur_mode"]["kernels"] = rk
+        except Exception as e:  # the record is optional
+            out["recursive_blur_mode"]["kernels"] = {"error": str(e)[:200]}
 
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
         scorer.set_reference(ref)

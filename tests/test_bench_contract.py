@@ -166,3 +166,30 @@ def test_cpu_baseline_keeps_the_fixed_slice_unless_another_is_clearly_faster(mon
     cb = bench.measure_cpu_baseline(3840, 2160, 8.2944)
     assert cb["pinned_to_cpus"] == "4-7" and not cb["placement"]["chosen_is_fixed_slice"] and calls[-1] == ((4, 5, 6, 7), 12.0)
     assert [k["cpus"] for k in cb["placement"]["candidates"]] == ["0-3", "4-7", "8-11"]
+
+
+def test_recursive_pass_kernels_carry_their_rooflines():
+    """`recursive_blur_mode.kernels`: the three launches of the search path's default pass with algorithmic bytes,
+    the kernel-trace averages of the round's committed rocprofv3 summary and the fraction of HBM peak -- and the
+    sum of the three is the pass (the live whole-pass time beside it)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    w, h = 3840, 2160
+    n_pad = sum((((w + (1 << k) - 1) >> k) + 127) // 128 * 128 * ((h + (1 << k) - 1) >> k) for k in range(6))
+    rk = bench.recursive_kernel_rooflines(w, h, n_pad, 0.365)
+    assert rk and rk["source"].startswith("profiles/r") and rk["peak_GBps"] == 8000.0
+    ks = {k["kernel"]: k for k in rk["kernels"]}
+    assert set(ks) == {"k_pyramid_bands_xyb", "k_rg_h<false, false>", "k_rg_v<false>"}
+    plane = n_pad * 4
+    assert ks["k_rg_v<false>"]["algorithmic_bytes"] == 21 * plane and ks["k_rg_h<false, false>"]["algorithmic_bytes"] == 15 * plane
+    for k in ks.values():
+        assert abs(k["achieved_GBps"] - k["algorithmic_bytes"] / k["ms"] / 1e6) < 1.0
+        assert 0.3 < k["frac_of_hbm_peak"] < 1.0 and abs(k["frac_of_hbm_peak"] - k["achieved_GBps"] / 8000.0) < 1e-3
+    assert abs(rk["sum_of_kernels_ms"] - sum(k["ms"] for k in ks.values())) < 1e-3
+    assert bench.recursive_kernel_rooflines(1920, 1080, n_pad, 0.1) is None          # the record is a 4K one
+    line = _line()
+    if "kernels" in line.get("recursive_blur_mode", {}):
+        rec = line["recursive_blur_mode"]
+        assert abs(rec["kernels"]["sum_of_kernels_ms"] - rec["cached_reference"]["ms_per_pass"]) < 0.03
