@@ -799,6 +799,35 @@ def main() -> int:
             except Exception as e:
                 out["quantizer_match_vs_cpu"] = {"error": str(e)}
 
+        # ---- external pin on the device: the calibration ladder SSIMULACRA2 was published with (libjpeg-turbo
+        # quality 14 ... 95 <-> scores 10 ... 90; tests/photo_ladder.py) on the two photographs scikit-learn ships,
+        # scored by the HIP path in both blur modes.  Not a timing: a sanity line beside `quantizer_match_vs_cpu` ----
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from photo_ladder import LADDER, jpeg_round_trip, photographs
+                photos = photographs()
+                if photos:
+                    rungs = []
+                    with oavif_amd.Ssimu2(local_rank, blur=oavif_amd._lib.BLUR_RECURSIVE) as rsc2:
+                        for q_, sub_, pub_ in LADDER:
+                            f_, r_ = [], []
+                            for _n, ph in photos:
+                                dj = jpeg_round_trip(ph, q_, sub_)
+                                f_.append(scorer.compute_ssimu2(ph, dj))
+                                r_.append(rsc2.compute_ssimu2(ph, dj))
+                            rungs.append({"libjpeg_quality": q_, "subsampling": {2: "4:2:0", 1: "4:2:2", 0: "4:4:4"}[sub_],
+                                          "published_score": pub_, "hip_fir_mean": round(float(np.mean(f_)), 2),
+                                          "hip_recursive_mean": round(float(np.mean(r_)), 2)})
+                    out["published_quality_ladder"] = {
+                        "rungs": rungs, "photographs": [n for n, _ in photos],
+                        "max_abs_deviation_recursive": round(max(abs(r["hip_recursive_mean"] - r["published_score"]) for r in rungs), 2),
+                        "note": "weak EXTERNAL pin: the table is the published calibration of SSIMULACRA2 (average output of "
+                                "each libjpeg-turbo setting over the authors' corpus), the images are two photographs; "
+                                "fssimu2 parity itself stays unpinned"}
+            except Exception as e:
+                out["published_quality_ladder"] = {"error": str(e)[:200]}
+
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:
             try:
