@@ -114,13 +114,15 @@ int oavif_tq_search_hip(const oavif_tq_options* o, ssimu2_ctx* scorer, const uin
    Return 0 on success; any other value aborts the search and is returned by it. */
 typedef int (*oavif_tq_batch_probe_fn)(void* user, const uint32_t* qs, uint32_t n, double* out_scores);
 
+/* ABI guard of oavif_tq_spec_options: a tag in the upper half + the struct's size as the CALLER compiled it in the
+   lower half.  The struct grew once (round 2's layout was {max_fanout, first_wave_fanout}); a plain size would not
+   tell that layout apart -- its max_fanout = 12 reads as "size 12" -- while no legal member value (fan-outs are
+   1..OAVIF_TQ_MAX_FANOUT) reaches the tag.  The library accepts exactly the value of its own header and refuses
+   everything else with SSIMU2_ERR_INVALID_ARG.  OAVIF_TQ_SPEC_OPTIONS_INIT fills it in. */
+#define OAVIF_TQ_SPEC_OPTIONS_TAG 0x71530000u
 typedef struct {
-    /* sizeof(oavif_tq_spec_options) as the CALLER compiled it (ABI guard, since library version v7: the struct
-       grew once already, and a caller built against a shorter layout would have the library read whatever
-       follows its struct).  The library refuses a size it does not know with SSIMU2_ERR_INVALID_ARG; members
-       beyond a known shorter size take their defaults.  OAVIF_TQ_SPEC_OPTIONS_INIT fills it in. */
-    uint32_t struct_size;
-    uint32_t max_fanout; /* probes per wave, 1..OAVIF_TQ_MAX_FANOUT; 1 = the sequential search */
+    uint32_t struct_size; /* OAVIF_TQ_SPEC_OPTIONS_TAG | sizeof(oavif_tq_spec_options) */
+    uint32_t max_fanout;  /* probes per wave, 1..OAVIF_TQ_MAX_FANOUT; 1 = the sequential search */
     /* Probes of the FIRST wave, 1..max_fanout; 0 = max_fanout.  The first probe of a search is the
        model's guess (tq.zig:40-43), and many searches end on it: with 1 the first wave is that
        probe alone, so a one-pass search costs exactly what the sequential search costs (no extra
@@ -129,7 +131,7 @@ typedef struct {
     uint32_t first_wave_fanout;
 } oavif_tq_spec_options;
 #define OAVIF_TQ_SPEC_OPTIONS_INIT(max_fanout_, first_wave_fanout_) \
-    { (uint32_t)sizeof(oavif_tq_spec_options), (max_fanout_), (first_wave_fanout_) }
+    { OAVIF_TQ_SPEC_OPTIONS_TAG | (uint32_t)sizeof(oavif_tq_spec_options), (max_fanout_), (first_wave_fanout_) }
 
 typedef struct {
     uint32_t waves;         /* calls of `batch` (the latency of the search, in passes)          */

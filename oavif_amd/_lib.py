@@ -68,11 +68,13 @@ class PngInfo(ctypes.Structure):   # oavif_png_info (include/oavif_tq.h)
 
 
 class TQSpecOptions(ctypes.Structure):
-    """oavif_tq_spec_options; struct_size is the ABI guard (include/oavif_tq.h), filled in here."""
+    """oavif_tq_spec_options; struct_size = OAVIF_TQ_SPEC_OPTIONS_TAG | sizeof is the ABI guard
+    (include/oavif_tq.h), filled in here."""
+    TAG = 0x71530000
     _fields_ = [("struct_size", ctypes.c_uint32), ("max_fanout", ctypes.c_uint32), ("first_wave_fanout", ctypes.c_uint32)]
 
     def __init__(self, max_fanout: int = 1, first_wave_fanout: int = 0):
-        super().__init__(ctypes.sizeof(TQSpecOptions), int(max_fanout), int(first_wave_fanout))
+        super().__init__(self.TAG | ctypes.sizeof(TQSpecOptions), int(max_fanout), int(first_wave_fanout))
 
 
 class TQSpecStats(ctypes.Structure):

@@ -8,8 +8,9 @@
 // loop be what fast inflaters are made of: a 64-bit bit buffer refilled eight bytes at a time, one table look-up
 // per literal / length / distance with the extra-bit counts and bases packed in the entry, and eight-byte match
 // copies.  Input is ONE contiguous buffer followed by at least kPad zero bytes (the caller concatenates the IDAT
-// chunks), so the refill never tests for the end of input; reading past the real end is detected afterwards
-// (`overrun()`), as a truncated stream.
+// chunks), so a refill never reads outside the buffer: it stops once `in` has passed the real end (at most 7 bytes into
+// the padding), after which the bit count runs negative and the block ends in an error; a stream that ends exactly
+// inside the padding is detected afterwards (`overrun()`), as a truncated stream.
 //
 // Checked against zlib itself (tests/c/inflate_diff.cpp, run by tests/test_sanitizers.py under ASan + UBSan):
 // every level and strategy of deflate over random, structured and degenerate data, decoded through strips of
@@ -69,19 +70,24 @@ inline uint64_t load64(const uint8_t* p) {
     return v;  // little-endian host (x86-64)
 }
 
-// Canonical Huffman decode table: primary table of `tbits` bits, subtables for longer codes.  `kind_of(sym)`
-// supplies the payload of a symbol.  Returns false for an over-subscribed code; an incomplete code leaves unused
-// slots as kBad (an error only if the stream reaches one), which is what lets a single-code distance tree through.
+// Canonical Huffman decode table: primary table of `tbits` bits, subtables for longer codes.  `payload(sym)`
+// supplies the payload of a symbol.  Returns false for an over-subscribed code, and for an incomplete one under
+// zlib's rule (inftrees.c): the code-length alphabet (`strict`) must be complete; a literal/length or distance code
+// may be incomplete only when it has no codes longer than one bit (the single-code distance tree deflate writes for
+// a block with one distance, or no distance codes at all) -- its unused slots stay kBad, an error only if the
+// stream reaches one.  A corrupted IDAT that zlib / libspng report as a decode failure fails here too.
 template <typename Payload>
-inline bool build_table(uint32_t* table, int table_cap, int tbits, const uint8_t* lens, int nsyms, Payload payload) {
+inline bool build_table(uint32_t* table, int table_cap, int tbits, const uint8_t* lens, int nsyms, bool strict, Payload payload) {
     int count[16] = {0};
     for (int i = 0; i < nsyms; ++i) ++count[lens[i]];
     count[0] = 0;
-    int left = 1;
+    int left = 1, maxlen = 0;
     for (int l = 1; l <= 15; ++l) {
         left = (left << 1) - count[l];
         if (left < 0) return false;  // over-subscribed
+        if (count[l]) maxlen = l;
     }
+    if (left > 0 && maxlen > 0 && (strict || maxlen != 1)) return false;  // incomplete set
     int offs[16];
     offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
@@ -182,6 +188,9 @@ inline bool read_block_header(Stream& s) {
         s.in -= s.bitcnt >> 3;
         s.bitbuf = 0;
         s.bitcnt = 0;
+        // LEN / NLEN were (partly) the zero padding: 0xFFFF / 0x0000 passes the complement test, so a stream cut
+        // inside a stored header must be caught by position (the refill above is skipped once `in` is past the end)
+        if (s.in > s.in_end) return false;
         s.stored_left = len;
         s.state = 1;
         return true;
@@ -190,12 +199,12 @@ inline bool read_block_header(Stream& s) {
     int nlit, ndist;
     if (type == 1) {
         nlit = 288;
-        ndist = 30;
+        ndist = 32;  // the fixed distance code is the complete 5-bit one; its symbols 30 and 31 are invalid (dist_payload)
         for (int i = 0; i < 144; ++i) lens[i] = 8;
         for (int i = 144; i < 256; ++i) lens[i] = 9;
         for (int i = 256; i < 280; ++i) lens[i] = 7;
         for (int i = 280; i < 288; ++i) lens[i] = 8;
-        for (int i = 0; i < 30; ++i) lens[288 + i] = 5;
+        for (int i = 0; i < 32; ++i) lens[288 + i] = 5;
     } else if (type == 2) {
         nlit = (int)(s.bitbuf & 31) + 257;
         ndist = (int)((s.bitbuf >> 5) & 31) + 1;
@@ -213,7 +222,7 @@ inline bool read_block_header(Stream& s) {
             s.bitcnt -= 3;
         }
         uint32_t ptab[(1 << kPreBits) + 8];
-        if (!build_table(ptab, (1 << kPreBits) + 8, kPreBits, pre, 19, [](int sym) { return kLit | ((uint32_t)sym << 16); }))
+        if (!build_table(ptab, (1 << kPreBits) + 8, kPreBits, pre, 19, true, [](int sym) { return kLit | ((uint32_t)sym << 16); }))
             return false;
         int i = 0;
         while (i < nlit + ndist) {
@@ -254,8 +263,8 @@ inline bool read_block_header(Stream& s) {
         return false;
     }
     if (s.bitcnt < 0) return false;
-    if (!build_table(s.lit, kLitSize, kLitBits, lens, type == 1 ? 288 : nlit, litlen_payload)) return false;
-    if (!build_table(s.dist, kDistSize, kDistBits, lens + 288, ndist, dist_payload)) return false;
+    if (!build_table(s.lit, kLitSize, kLitBits, lens, type == 1 ? 288 : nlit, false, litlen_payload)) return false;
+    if (!build_table(s.dist, kDistSize, kDistBits, lens + 288, ndist, false, dist_payload)) return false;
     s.state = 2;
     return true;
 }
@@ -267,7 +276,6 @@ inline bool read_block_header(Stream& s) {
 inline Result run(Stream& s, const uint8_t* out_begin, uint8_t*& out, uint8_t* out_end) {
     for (;;) {
         if (s.state == 3) return kDone;
-        if (s.in > s.in_end + 8) return kError;  // far into the padding: a truncated stream that decodes zeros
         if (s.state == 0) {
             if (!read_block_header(s)) return kError;
             continue;
@@ -277,7 +285,8 @@ inline Result run(Stream& s, const uint8_t* out_begin, uint8_t*& out, uint8_t* o
                 size_t n = s.stored_left;
                 if ((size_t)(out_end - out) < n) n = (size_t)(out_end - out);
                 if (n == 0) return kNeedOutput;
-                if ((size_t)(s.in_end - s.in) < n) return kError;  // truncated
+                const size_t avail = s.in < s.in_end ? (size_t)(s.in_end - s.in) : 0;
+                if (avail < n) return kError;  // truncated
                 memcpy(out, s.in, n);
                 out += n;
                 s.in += n;
@@ -309,7 +318,6 @@ inline Result run(Stream& s, const uint8_t* out_begin, uint8_t*& out, uint8_t* o
                 res = kNeedOutput;
                 break;
             }
-            if (in > in_end + 8) break;  // error: ran far past the end of input
             REFILL();  // >= 56 bits: a litlen code (15) + extra (5) + a distance code (15) + extra (13) = 48
             uint32_t e = lit[bitbuf & ((1u << kLitBits) - 1)];
             if ((e >> 12 & 0xf) == 4) e = lit[(e >> 16) + ((bitbuf >> kLitBits) & ((1u << (e >> 8 & 0xf)) - 1))];

@@ -191,6 +191,7 @@ typedef struct {
     double tolerance;
     int max_pass, quality /* -1 = search */, color_primaries, transfer_characteristics, matrix_coefficients;
 } Options;
+#define OPTIONS_DEFAULT {0, 9, 1, 0, 0, 1, 80.0, 1, "iq", 2.0, 6, -1, 2, 2, 2} /* parse_args.zig:48-63 */
 
 static int int_arg(int* i, int argc, char** argv, long lo, long hi, const char* name, int* out) {
     if (*i >= argc || argv[*i][0] == '-') { /* parse_args.zig:126: a value starting with '-' counts as missing */
@@ -286,13 +287,24 @@ typedef struct {
 static uint8_t* read_file(const char* path, size_t* len) {
     FILE* f = fopen(path, "rb");
     if (!f) { fail("FileNotFound", path); return NULL; }
-    fseek(f, 0, SEEK_END);
-    const long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    uint8_t* b = (uint8_t*)malloc(n > 0 ? (size_t)n : 1);
-    if (!b || fread(b, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(b); fail("ReadFailed", path); return NULL; }
+    /* Read until end of file into a growing buffer: a FIFO or another non-seekable input named x.png has no size to
+       ask for (ftell gives -1 there; ADVICE r04: that became malloc(1) + fread of SIZE_MAX bytes). */
+    size_t cap = 1u << 16, n = 0;
+    struct stat st;
+    if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) cap = (size_t)st.st_size + 1;
+    uint8_t* b = (uint8_t*)malloc(cap);
+    while (b) {
+        n += fread(b + n, 1, cap - n, f);
+        if (n < cap) break; /* short read: end of file or an error */
+        if (cap > SIZE_MAX / 2) { free(b); b = NULL; break; }
+        uint8_t* g = (uint8_t*)realloc(b, cap * 2);
+        if (!g) { free(b); b = NULL; break; }
+        b = g;
+        cap *= 2;
+    }
+    if (!b || ferror(f)) { fclose(f); free(b); fail(b ? "ReadFailed" : "OutOfMemory", path); return NULL; }
     fclose(f);
-    *len = (size_t)n;
+    *len = n;
     return b;
 }
 
@@ -669,7 +681,7 @@ static void phase(const char* what) { /* OAVIF_HOST_TIMES: where a one-image run
 }
 
 static int run_inner(Run* r, int argc, char** argv) {
-    Options o = {0, 9, 1, 0, 0, 1, 80.0, 1, "iq", 2.0, 6, -1, 2, 2, 2}; /* parse_args.zig:48-63 */
+    Options o = OPTIONS_DEFAULT;
     const char *in = NULL, *out = NULL;
     if (parse_args(&o, argc, argv, &in, &out)) return -1;
     if (!in || !out) return fail("MissingInputOrOutput", NULL);
@@ -823,8 +835,50 @@ static int run(int argc, char** argv) {
     return rc;
 }
 
+/* parse_args.zig:180-238: the usage text with the defaults of the options struct filled in */
+static void print_usage(void) {
+    const Options d = OPTIONS_DEFAULT;
+    fprintf(stderr,
+            "\nusage:  oavif [options] <in> <out.avif>\n\noptions:\n"
+            " -h, --help\n    show this help\n"
+            " -v, --version\n    show version information\n"
+            " -s, --speed u8\n    encoder speed (0..10) [%d]\n"
+            " -t, --score-tgt f64\n    target SSIMULACRA2 score (0..100) [%.0f]\n"
+            " --quality-alpha u8\n    quality factor for alpha (0..100=lossless) [%d]\n"
+            " --max-threads u8\n    maximum number of threads to use (1..255) [%d]\n"
+            " --tile-rows-log2 u8\n    tile rows log2 (0..6) [%d]\n"
+            " --tile-cols-log2 u8\n    tile columns log2 (0..6) [%d]\n"
+            " --auto-tiling 0/1\n    enable automatic tiling [%d]\n"
+            " --tune str\n    libaom tuning mode (ssim, iq, ssimulacra2) [%s]\n"
+            " --tenbit 0/1\n    force 10-bit AVIF output [%d]\n"
+            " --tolerance f64\n    target quality error tolerance (1..100) [%.0f]\n"
+            " --max-pass u8\n    maximum search passes (1..12) [%d]\n"
+            " -q, --quality u8\n    quantizer (0..100), bypasses search\n"
+            " --color-primaries u8\n    color primaries (1..22) [%d]\n"
+            " --transfer-characteristics u8\n    transfer characteristics (1..18) [%d]\n"
+            " --matrix-coefficients u8\n    matrix coefficients (0..14) [%d]"
+            "\n\n\x1b[37mInput image formats: PNG, PAM, JPEG, WebP, or AVIF\x1b[0m\n",
+            d.speed, d.score_tgt, d.quality_alpha, d.max_threads, d.tile_rows_log2, d.tile_cols_log2, d.auto_tiling, d.tune,
+            d.tenbit, d.tolerance, d.max_pass, d.color_primaries, d.transfer_characteristics, d.matrix_coefficients);
+}
+
+/* io.printVersion (io.zig:14-39) for what this host links: itself, the scorer library, libavif and its codecs */
+static void print_version(void) {
+    fprintf(stderr, "oavif %s\nscorer %s\n", VERSION, ssimu2_version());
+    if (load_libavif() == 0) fprintf(stderr, "libavif %s\n", av.Version());
+}
+
 int main(int argc, char** argv) {
     fprintf(stderr, "\x1b[31moavif\x1b[0m | %s\n", VERSION);
+    /* main.zig:46-61: -h/--help and -v/--version count only while they are the leading arguments */
+    int show_help = 0, show_version = 0;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) show_help = 1;
+        else if (!strcmp(argv[i], "--version") || !strcmp(argv[i], "-v")) show_version = 1;
+        else break;
+    }
+    if (show_help) { print_usage(); return 0; }
+    if (show_version) { print_version(); return 0; }
     int rc = 0;
     if (run(argc, argv)) {
         fprintf(stderr, "error: %s%s%s\n", g_err ? g_err : "Unexpected", g_detail[0] ? ": " : "", g_detail);

@@ -317,11 +317,12 @@ int oavif_tq_find_target_quality_speculative(const oavif_tq_options* o,
                                              oavif_tq_batch_probe_fn batch, void* user,
                                              oavif_tq_result* out, oavif_tq_spec_stats* stats) {
     if (!o || !so || !batch || !out) return SSIMU2_ERR_INVALID_ARG;
-    // ABI guard: the layouts this library knows are {struct_size, max_fanout} (12 bytes would be today's;
-    // 8 = a caller that stops before first_wave_fanout, which then takes its default 0 = max_fanout)
-    if (so->struct_size != sizeof(oavif_tq_spec_options) && so->struct_size != 2 * sizeof(uint32_t))
+    // ABI guard (include/oavif_tq.h): exactly this header's tag | size.  Round 2's untagged {max_fanout,
+    // first_wave_fanout} cannot produce it, so such a caller gets an error instead of a misparsed fan-out
+    // ({8, 1} used to read as "size 8, max_fanout 1" -- a silent sequential search).
+    if (so->struct_size != (OAVIF_TQ_SPEC_OPTIONS_TAG | (uint32_t)sizeof(oavif_tq_spec_options)))
         return SSIMU2_ERR_INVALID_ARG;
-    const uint32_t first_wave = so->struct_size >= sizeof(oavif_tq_spec_options) ? so->first_wave_fanout : 0u;
+    const uint32_t first_wave = so->first_wave_fanout;
     if (so->max_fanout < 1 || so->max_fanout > OAVIF_TQ_MAX_FANOUT) return SSIMU2_ERR_INVALID_ARG;
     if (first_wave > so->max_fanout) return SSIMU2_ERR_INVALID_ARG;
     Spec s{};

@@ -136,8 +136,56 @@ int main(int argc, char** argv) {
                 // (none known); report it
                 fprintf(stderr, "NOTE zlib accepts, fast refuses (rc %d): round %d case %d\n", frc, r, c);
                 return 1;
+            } else if (zrc != 0 && frc == 0) {
+                // the other direction: a stream zlib -- and so libspng, the reference's PNG decoder --
+                // reports as a decode failure must not turn into pixels here (e.g. incomplete Huffman codes)
+                fprintf(stderr, "NOTE fast accepts, zlib refuses: round %d case %d\n", r, c);
+                return 1;
             }
         }
+    }
+    // a stored block whose header is cut by the end of input.  LEN = 0xFFFF reads the zero padding
+    // as NLEN = 0x0000 and passes the complement test; the decoder must report the truncation by position instead of
+    // copying 65535 bytes from behind its input.  Every prefix of a level-0 stream's last block header, the 4-byte
+    // stream of the finding itself, and a hand-made incomplete literal/length code.
+    {
+        long cut = 0;
+        Bytes src65535 = make_data(0, 65535);
+        const Bytes whole = deflate_raw(src65535, 0, Z_DEFAULT_STRATEGY, 8);  // 01 FF FF 00 00 <65535 bytes>
+        for (size_t keep = 0; keep < 12 && keep < whole.size(); ++keep) {
+            Bytes bad(whole.begin(), whole.begin() + (long)keep), zout, fout;
+            const int zrc = zlib_inflate_raw(bad, 70000, zout);
+            for (size_t strip : strips) {
+                const int frc = fast_inflate(bad, strip, 70000, fout);
+                if (zrc == 0 || frc == 0) {
+                    fprintf(stderr, "MISMATCH stored stream cut after %zu bytes: zlib %d fast %d\n", keep, zrc, frc);
+                    return 1;
+                }
+                ++cut;
+            }
+        }
+        Bytes two = make_data(0, 65535 + 300);  // two stored blocks: cut inside the SECOND header as well
+        const Bytes whole2 = deflate_raw(two, 0, Z_DEFAULT_STRATEGY, 8);
+        for (size_t keep = 65535 + 5; keep <= 65535 + 5 + 6 && keep < whole2.size(); ++keep) {
+            Bytes bad(whole2.begin(), whole2.begin() + (long)keep), zout, fout;
+            const int zrc = zlib_inflate_raw(bad, 140000, zout);
+            const int frc = fast_inflate(bad, 4093, 140000, fout);
+            if (zrc == 0 || frc == 0) {
+                fprintf(stderr, "MISMATCH second stored header cut at %zu: zlib %d fast %d\n", keep, zrc, frc);
+                return 1;
+            }
+            ++cut;
+        }
+        static const uint8_t finding[4] = {0x01, 0xFF, 0xFF, 0x00};
+        for (size_t keep = 1; keep <= 4; ++keep) {
+            Bytes bad(finding, finding + keep), zout, fout;
+            if (zlib_inflate_raw(bad, 70000, zout) == 0 || fast_inflate(bad, 65536, 70000, fout) == 0) {
+                fprintf(stderr, "MISMATCH the 4-byte stored header of ADVICE r04 (first %zu bytes) is accepted\n", keep);
+                return 1;
+            }
+            ++cut;
+        }
+        printf("inflate_diff: %ld truncated stored headers refused by both decoders\n", cut);
     }
     printf("inflate_diff ok: %ld valid decodes identical to the source, %ld corrupted streams (%ld accepted by both, same bytes)\n",
            valid, corrupt, both_ok);

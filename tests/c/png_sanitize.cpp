@@ -132,6 +132,31 @@ int main(int argc, char** argv) {
                 }
             }
     }
+    // a 40 x 40 RGB8 file whose IDAT is a zlib header + a stored block header cut after LEN and
+    // the first byte of NLEN (78 01 | 01 FF FF 00): the zero padding behind the input completed NLEN, and the inflater
+    // copied 65535 bytes from behind the IDAT bytes into the caller's pixels.  Every prefix of such an IDAT must be
+    // refused, with nothing read outside the file (ASan).
+    {
+        static const uint8_t idat[] = {0x78, 0x01, 0x01, 0xFF, 0xFF, 0x00, 0x00};
+        for (size_t keep = 2; keep <= sizeof idat; ++keep) {
+            Bytes png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A}, d;
+            put32(d, 40);
+            put32(d, 40);
+            d.push_back(8);
+            d.push_back(2);
+            d.push_back(0);
+            d.push_back(0);
+            d.push_back(0);
+            chunk(png, "IHDR", d);
+            chunk(png, "IDAT", Bytes(idat, idat + keep));
+            chunk(png, "IEND", Bytes());
+            std::vector<uint8_t> px(40 * 40 * 3);
+            if (oavif_png_decode(png.data(), png.size(), px.data(), px.size(), nullptr, 0) == OAVIF_PNG_OK) {
+                printf("a stored block cut inside its header (IDAT of %zu bytes) decoded\n", keep);
+                return 1;
+            }
+        }
+    }
     long ok = 0, rejected = 0;
     for (int r = 0; r < rounds; ++r)
         for (const Bytes& s : seeds) {

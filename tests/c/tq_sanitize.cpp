@@ -182,16 +182,23 @@ int main(int argc, char** argv) {
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
         so.max_fanout = OAVIF_TQ_MAX_FANOUT + 1;
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
-        // the ABI guard: a struct_size the library does not know is refused; the round-2 layout (no
-        // first_wave_fanout behind max_fanout) is accepted and means first_wave_fanout = 0
+        // the ABI guard: only this header's tag | size is accepted.  A bare size (12, or the 8 an earlier
+        // library took for "stops before first_wave_fanout") and round 2's untagged {max_fanout,
+        // first_wave_fanout} -- whose legal fan-outs 8 and 12 used to read as sizes -- are refused
         so.max_fanout = 4;
-        so.struct_size = 4;
-        CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
-        so.struct_size = 64;
-        CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
-        so.struct_size = 8;
-        so.first_wave_fanout = 0xFFFFFFFFu;  // not read at this size
+        const uint32_t good = so.struct_size;
+        CHECK(good == (OAVIF_TQ_SPEC_OPTIONS_TAG | 12u));
         CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) == 0);
+        for (uint32_t bad : {4u, 8u, 12u, 64u, OAVIF_TQ_SPEC_OPTIONS_TAG | 8u, OAVIF_TQ_SPEC_OPTIONS_TAG | 16u, OAVIF_TQ_SPEC_OPTIONS_TAG}) {
+            so.struct_size = bad;
+            CHECK(oavif_tq_find_target_quality_speculative(&o, &so, table_batch, &t, &r, &st) != 0);
+        }
+        for (uint32_t old_fan = 1; old_fan <= OAVIF_TQ_MAX_FANOUT; ++old_fan)
+            for (uint32_t old_first = 0; old_first <= old_fan; ++old_first) {
+                const uint32_t old_layout[3] = {old_fan, old_first, 0xFFFFFFFFu};   // what a round-2 caller's memory holds
+                CHECK(oavif_tq_find_target_quality_speculative(&o, (const oavif_tq_spec_options*)old_layout, table_batch, &t, &r, &st) != 0);
+            }
+        so.struct_size = good;
         o.max_pass = 0;
         CHECK(oavif_tq_find_target_quality(&o, table_probe, &t, &r) != 0);
         o.max_pass = OAVIF_TQ_MAX_PASS + 1;

@@ -144,6 +144,33 @@ def test_argument_errors_carry_the_references_names(host, tmp_path):
     assert r.returncode == 1 and "error: LibavifUnavailable" in r.stderr
 
 
+def test_help_and_version_lead_and_a_fifo_input_is_read_to_its_end(host, tmp_path, capsys):
+    """(i) main.zig:46-61 -- -h / --help / -v / --version are honoured while they are the leading
+    arguments (the usage text is parse_args.zig:180-238's, the Python mirror prints the same); behind another
+    argument `-h` is an ordinary (unknown) argument.  (ii) a non-seekable input (a FIFO named x.pam) is read until
+    end of file instead of by ftell's -1."""
+    import threading
+    r = _run(host, ["-h"])
+    assert r.returncode == 0 and "usage:  oavif [options] <in> <out.avif>" in r.stderr
+    cli.print_usage()
+    mirror = capsys.readouterr().err
+    assert r.stderr.split("\n", 1)[1].strip() == mirror.strip()
+    assert "show this help" in _run(host, ["--version", "--help", "whatever"]).stderr   # help wins (main.zig:60-61)
+    v = _run(host, ["-v"])
+    assert v.returncode == 0 and "scorer oavif_amd ssimu2 gfx950" in v.stderr and "libavif" in v.stderr
+    assert _run(host, ["-q", "50", "-h", "x"]).returncode == 1
+    _ref, _png, p = _inputs(tmp_path, 40, 24)
+    fifo = tmp_path / "pipe.pam"
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: fifo.open("wb").write(p.read_bytes()))
+    t.start()
+    r = _run(host, ["-q", "50", "--tenbit", "0", str(fifo), str(tmp_path / "f.avif")])
+    t.join()
+    assert r.returncode == 0, r.stderr
+    assert _run(host, ["-q", "50", "--tenbit", "0", str(p), str(tmp_path / "g.avif")]).returncode == 0
+    assert (tmp_path / "f.avif").read_bytes() == (tmp_path / "g.avif").read_bytes()
+
+
 def test_search_without_a_gpu_fails_loudly(host, tmp_path):
     import torch
     if torch.cuda.is_available():
