@@ -28,6 +28,13 @@ Extra objects on the JSON line:
                   stamped with the kernel source hash; a mismatch is reported as "stale".
   cpu_baseline -- the repo's CPU oracle ("port"; the reference's Zig+fssimu2 path cannot be
                   built: no Zig, fssimu2 source absent) timed on this host, rank 0, N = 1 only.
+  collective   -- what the process group really was (oavif_amd/collective.py): backend, world size, and per
+                  rank the host, HIP device index, PCI bus id, NUMA node and pinned cores, gathered over the
+                  job's own process group (device tensors through RCCL when the backend is nccl; at N = 1 a
+                  process group of one rank is opened for it after the timed region).  The run exits non-zero
+                  (rc 4) when two RCCL ranks report one GPU or the host shows fewer devices than ranks.
+  default_search_mode -- throughput of the mode the SEARCH path runs by default (the published recursion, one
+                  cached-reference pass per probe), beside `value` (FIR pair scoring, two contexts).
 """
 from __future__ import annotations
 
@@ -112,19 +119,28 @@ def recursive_kernel_rooflines(w: int, h: int, n_pad: int, live_pass_ms: float):
                     rows[key] = float(r["AverageNs"]) * 1e-6
     if len(rows) != len(want):
         return None
+    ceil = {"read": 6000.0, "write": 5600.0, "mixed": 5100.0}   # GB/s, profiles/r04_rw_mix.txt (2:3 / 1:1 read:write streams)
+    which = {"k_pyramid_bands_xyb": "mixed", "k_rg_h<false, false>": "mixed", "k_rg_v<false>": "read"}
     ks = []
     for key, (what, nbytes) in want.items():
-        ks.append({"kernel": key, "what": what, "ms": round(rows[key], 4), "algorithmic_bytes": int(nbytes),
-                   "achieved_GBps": round(nbytes / rows[key] / 1e6, 1), "frac_of_hbm_peak": round(nbytes / rows[key] / 1e6 / 8000.0, 3)})
-    return {"source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --kernel-trace --stats, committed with the round)",
-            "sum_of_kernels_ms": round(sum(rows.values()), 4), "live_ms_per_pass": round(live_pass_ms, 4), "peak_GBps": 8000.0,
-            "measured_stream_ceilings_GBps": {"read": 6000, "write": 5600, "mixed": 5100,
-                                              "source": "profiles/r04_rw_mix.txt"},
+        gbps = nbytes / rows[key] / 1e6
+        ks.append({"kernel": key, "what": what, "ms": round(rows[key], 4), "ms_measured_by_this_run": False,
+                   "algorithmic_bytes": int(nbytes), "achieved_GBps": round(gbps, 1),
+                   "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 3),
+                   "frac_of_measured_stream_ceiling": round(gbps / ceil[which[key]], 3), "ceiling": which[key]})
+    moved = sum(k["algorithmic_bytes"] for k in ks)
+    strict = w * h * 3 + 9 * plane    # the distorted frame's bytes + the nine cached reference planes it is compared with
+    return {"source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --kernel-trace --stats of scripts/gpu_rg_bench.py, "
+                      "committed with the round it names; NOT measured by this run -- `live_ms_per_pass` is)",
+            "sum_of_kernels_ms": round(sum(rows.values()), 4), "live_ms_per_pass": round(live_pass_ms, 4),
+            "live_over_sum_of_kernels": round(live_pass_ms / sum(rows.values()), 3), "peak_GBps": HBM_PEAK_GBS,
+            "measured_stream_ceilings_GBps": dict(ceil, source="profiles/r04_rw_mix.txt"),
             "kernels": ks,
-            "note": "all three are HBM-bound byte movers: the vertical pass reads at 0.95 of the measured read-stream "
-                    "ceiling, the horizontal pass and the conversion at 0.85 of the mixed one; what they move "
-                    "(1.75 GB per pass) is 4 x the strict minimum, the h -> v round trip of nine planes being the "
-                    "largest part (DESIGN.md section 4: why it stays)"}
+            "bytes_moved_per_pass_GB": round(moved / 1e9, 3), "strict_minimum_GB": round(strict / 1e9, 3),
+            "moved_over_strict_minimum": round(moved / strict, 2),
+            "note": "per-kernel fractions are computed from the byte counts and the CSV's durations; the h -> v round "
+                    "trip of nine planes is the largest part of what is moved beyond the strict minimum (DESIGN.md "
+                    "section 4: why it stays)"}
 
 
 def cpu_baseline_child(argv) -> int:
@@ -244,6 +260,42 @@ def measure_cpu_baseline(w, h, mp):
         "placement": info, "_score": full["score"]}
 
 
+def single_rank_collective(local_rank: int) -> dict:
+    """N = 1: the `collective` record still travels through RCCL -- a process group of ONE rank on backend "nccl"
+    (device_id = this GPU), the same all_gather of device tensors the N > 1 job starts with.  Opened after the timed
+    region so that RCCL's own streams cannot touch the measurement; bounded by a 60 s rendezvous timeout; any failure
+    is recorded, not raised (the throughput line does not depend on it)."""
+    import datetime
+    import socket
+    import torch
+    import torch.distributed as dist
+    from oavif_amd import collective
+    me = collective.rank_record(0, local_rank, local_rank, pinned=None)
+    if os.environ.get("OAVIF_BENCH_COLLECTIVE", "1") == "0":
+        return collective.describe("none", 1, [me], "not gathered (OAVIF_BENCH_COLLECTIVE=0)")
+    try:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=60))
+        try:
+            recs = collective.gather(me, torch.device("cuda", local_rank))
+            t_ = torch.tensor([1.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # the other collective of an N > 1 line (max over ranks)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+        bad = collective.problems(recs, "nccl", 1, 1, torch.cuda.device_count())
+        return collective.describe("nccl", 1, recs, "an RCCL process group of one rank (device tensors), opened after the "
+                                                   "timed region", bad)
+    except Exception as e:
+        c = collective.describe("nccl", 1, [me], "not gathered: the single-rank RCCL group failed")
+        c["error"] = f"{type(e).__name__}: {str(e)[:300]}"
+        return c
+
+
 def main() -> int:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         return cpu_baseline_child(sys.argv[2:])
@@ -260,13 +312,20 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    # A rank of a multi-rank job pins itself to its slice of the host cores near its GPU before torch / HIP start
+    # any thread (oavif_amd.hostinfo, as the batch driver does): the launch thread then sits on the GPU's NUMA node.
+    pinned = None
+    if world > 1 and os.environ.get("OAVIF_BENCH_NO_PIN", "") != "1":
+        from oavif_amd import hostinfo as _hi
+        pinned = bool(_hi.pin_rank(local_rank, local_world).pinned)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with "
@@ -280,6 +339,12 @@ def main() -> int:
     # mode for boxes with fewer GPUs than ranks: ranks share devices (local_rank modulo the
     # device count) and the collectives run on CPU tensors; never used for reported numbers.
     backend = os.environ.get("OAVIF_BENCH_BACKEND", "nccl")
+    from oavif_amd import collective
+    if distributed:
+        why = collective.preflight(backend, local_world)
+        if why:   # every rank of the host sees the same count: all leave with the same code, nobody waits in a rendezvous
+            print(f"bench.py: rank {rank}: refusing to run: {why}", file=sys.stderr)
+            return 4
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -293,6 +358,22 @@ def main() -> int:
 
     import oavif_amd
     from oavif_amd import synth
+
+    # The first thing the process group carries: every rank's description of itself.  A rank / device mix-up ends
+    # the run here (rc 4 on every rank: all of them judge the same gathered records), not in a plausible line.
+    coll = None
+    if distributed:
+        coll, bad = collective.check_in(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank, backend, world, local_world,
+                                        tensor_device=coll_dev if backend == "nccl" else None, pinned=pinned)
+        if backend != "nccl":
+            coll["note"] = "a rehearsal: ranks share devices and the collectives run on CPU tensors; never a reported number"
+        if bad:
+            if rank == 0:
+                print("bench.py: refusing to run:\n  " + "\n  ".join(bad), file=sys.stderr)
+                print(json.dumps({"metric": "ssimulacra2_megapixels_per_sec", "value": None, "error": "placement refused",
+                                  "n_gpus": world, "collective": coll}), flush=True)
+            dist.destroy_process_group()
+            return 4
 
     w, h = args.width, args.height
     mp = w * h / 1e6
@@ -435,6 +516,8 @@ def main() -> int:
                        "kernels": oavif_amd.version()},
             "scores": [round(s, 6) for s in scores],
         }
+        if coll is not None:
+            out["collective"] = coll
         out["cache_resident"] = {
             "value": round(args.steps * mp / elapsed_resident, 2),
             "unit": "MP/s per GPU", "ms_per_step": round(elapsed_resident / args.steps * 1e3, 5),
@@ -635,6 +718,16 @@ def main() -> int:
                     "(one workgroup per CU); the default of the SEARCH path (shim, CLI, batch) since round 4, "
                     "`value` stays the FIR mode"}
 
+        # the mode the SEARCH path runs by default (shim, CLI mirror, batch driver, C host): one cached-reference
+        # pass of the published recursion per probe -- beside `value`, which is FIR pair scoring on two contexts
+        out["default_search_mode"] = {
+            "blur": "recursive (SSIMU2_BLUR_RECURSIVE)", "what": "one cached-reference pass per probe, one stream, inputs in HBM",
+            "ms_per_pass": round(rc_ms, 4), "MP_per_s": round(mp / rc_ms * 1e3, 1),
+            "ms_per_pass_from_host_memory": round(r_host_ms, 4),
+            "value_is": "FIR pair scoring on two contexts (SSIMU2_BLUR_FIR, a bare context's mode): "
+                        f"{out['value']} MP/s; the same cached-reference pass in FIR mode: {out['cached_reference']['MP_per_s']} MP/s",
+            "parity": "both modes are checked against this repository's CPU oracle only; fssimu2 parity unpinned"}
+
         # per-kernel rooflines of the recursive pass: the three launches of a reference-cached pass with their
         # algorithmic bytes (planes as the kernels address them: rows padded to 128 floats) against the rocprofv3
         # kernel-trace averages committed with the round (the same source the PMC traffic of `roofline` comes
@@ -827,6 +920,10 @@ def main() -> int:
                                 "fssimu2 parity itself stays unpinned"}
             except Exception as e:
                 out["published_quality_ladder"] = {"error": str(e)[:200]}
+
+        # ---- N = 1: the collective record through a single-rank RCCL group (after every GPU measurement) ----
+        if world == 1:
+            out["collective"] = single_rank_collective(local_rank)
 
         # ---- CPU baseline: the oracle on this host's cores (N = 1 only) ----------------------
         if world == 1 and not args.no_cpu_baseline:

@@ -44,7 +44,9 @@ enum {
     SSIMU2_ERR_OOM = -3,           /* host or device allocation failed                  */
     SSIMU2_ERR_HIP = -4,           /* a HIP runtime call or kernel launch failed        */
     SSIMU2_ERR_NO_REFERENCE = -5,  /* score_against_reference without set_reference     */
-    SSIMU2_ERR_NO_DEVICE = -6      /* no usable gfx950 device                           */
+    SSIMU2_ERR_NO_DEVICE = -6      /* no usable gfx950 device: no HIP device of that index, a device
+                                      that is not gfx950 (the library holds gfx950 code only), or one
+                                      with less than 160 KB of LDS per compute unit                    */
 };
 
 /* Number of per-scale statistics and scales of the published algorithm: 6 scales x
@@ -57,10 +59,50 @@ enum {
    provides a non-blocking stream, and places it: HIP maps streams onto a few hardware queues and
    two streams on one queue do not overlap at all, so once per process and device the library
    probes a few streams and keeps a set that run side by side; the first contexts created borrow
-   those (three with HIP's default of four hardware queues), so the scores of any two of them
+   those (up to four; three or four are found with HIP's default of four hardware queues, depending on
+   where the null stream sits), so the scores of any two of them
    overlap (13 % more throughput at 4K than two contexts that share a queue); further contexts
    get a stream on whatever queue HIP picks. */
 int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx);
+
+/* What the library sees of a HIP device, and what ssimu2_ctx_create checks before anything is allocated: the
+   architecture must be gfx950 (`arch` starts with "gfx950": the code object holds nothing else, and a launch on
+   another device would fail at the first kernel) and a compute unit must have 160 KB of LDS (the vertical pass of
+   the recursive blur modes holds one workgroup per CU by asking for more than half a CU's LDS; on a 64 KB part the
+   launch would be refused).  A device that fails either check gives SSIMU2_ERR_NO_DEVICE from ssimu2_ctx_create,
+   with the reason in ssimu2_last_error(NULL).
+   ssimu2_query_device fills the record for ANY HIP device index (also one that ctx_create would refuse: `usable`
+   says which) without creating a context; ssimu2_ctx_device_info returns the record the context was created with.
+   `struct_size` must be sizeof(ssimu2_device_info) as the caller compiled it (SSIMU2_ERR_INVALID_ARG otherwise).
+   Multi-GPU launchers use pci_bus_id / numa_node to prove that every rank sits on a device of its own
+   (bench.py's and the batch driver's `collective` record). */
+typedef struct {
+    uint32_t struct_size;
+    int32_t device;                   /* HIP device index the record describes                              */
+    char arch[64];                    /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"                           */
+    char name[128];                   /* marketing name                                                      */
+    char pci_bus_id[32];              /* "0000:05:00.0" (domain:bus:device.function), lower case               */
+    uint32_t compute_units;
+    uint32_t lds_bytes_per_cu;        /* what the 160 KB check reads                                          */
+    uint32_t lds_bytes_per_workgroup; /* largest LDS allocation of one workgroup                              */
+    uint32_t wavefront_size;
+    uint64_t hbm_bytes;               /* total device memory                                                  */
+    int32_t numa_node;                /* host NUMA node the device hangs off (sysfs), -1 = unknown            */
+    int32_t usable;                   /* 1 = ssimu2_ctx_create accepts the device                             */
+} ssimu2_device_info;
+int ssimu2_query_device(int device, ssimu2_device_info* out);
+int ssimu2_ctx_device_info(const ssimu2_ctx* ctx, ssimu2_device_info* out);
+
+/* Page-locked ("pinned") host memory for frames handed to the host-pointer entry points below.  The reference
+   decodes every probe into a buffer libavif allocates (io.zig:452-482: avifRGBImageAllocatePixels) and the scorer
+   then reads it from pageable memory, which the HIP runtime first copies into a staging buffer of its own.  A host
+   that points avifRGBImage.pixels at a buffer from ssimu2_host_alloc instead (libavif fills any caller-provided
+   `pixels` / `rowBytes`) lets the upload run as one DMA from the decoder's own output.  Any pointer works with every
+   entry point; pinned ones only skip the staging copy.  The memory is visible to every device of the process; free
+   it with ssimu2_host_free (NULL is a no-op).  `ctx` names the device context of the allocation and receives the
+   error text. */
+int ssimu2_host_alloc(ssimu2_ctx* ctx, size_t bytes, void** out_ptr);
+int ssimu2_host_free(ssimu2_ctx* ctx, void* ptr);
 
 /* Optional: start the once-per-process initialisation of `device` (HIP runtime, code object,
    constant table -- 140-340 ms) on a background thread and return at once.  A later
@@ -80,14 +122,16 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
    which of the two it follows is not known:
      SSIMU2_BLUR_FIR        (default; the THROUGHPUT mode) the 9-tap impulse response of the
                             published sigma-1.5 recursive Gaussian, zero padding, fused kernels --
-                            what bench.py measures: 0.16 ms per 4K pass;
+                            what bench.py's `value` measures: 0.15 ms per 4K pass;
      SSIMU2_BLUR_RECURSIVE  (the CONSERVATIVE-PARITY mode) the published recursion itself (libjxl
                             FastGaussian: three second-order sections, products rounded to fp32
                             first, horizontal then vertical), operation for operation, planes
-                            bit-identical to the CPU checker's.  0.4 ms per 4K pass against a
+                            bit-identical to the CPU checker's.  0.37 ms per 4K pass against a
                             reference set with ssimu2_set_reference (whose XYB planes, blur(x) and
                             blur(x*x) are then cached, so a pass recurses 9 of the 15 planes),
-                            0.8 ms for a pair score.
+                            0.71 ms for a pair score (driver-run record BENCH_r04).  This is the mode
+                            the search path runs by default (the Zig shim, the CLI mirror, the batch
+                            driver and the C host set it); a bare context starts in SSIMU2_BLUR_FIR.
    The two differ by the recursion's own fp32 rounding noise, which grows with the line length:
    median 0.02 points on 384x256 frames, 0.13 at 1080p, 0.47 (max 2.4) at 4K; against the operator
    accumulated in fp64 the FIR form is within 0.0005 at 4K, the recursion about 1 point off.
@@ -163,7 +207,7 @@ int ssimu2_enqueue_against_reference_device(ssimu2_ctx* ctx, const void* d_dist)
 int ssimu2_last_averages(ssimu2_ctx* ctx, double out[SSIMU2_NUM_SCALES * SSIMU2_STATS_PER_SCALE],
                          int* out_num_scales);
 
-/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v6 (...)". */
+/* Library/build description, e.g. "oavif_amd ssimu2 gfx950 v8 (...)". */
 const char* ssimu2_version(void);
 
 #if defined(__GNUC__)

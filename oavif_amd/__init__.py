@@ -6,7 +6,7 @@ Scope: /root/reference/src/tq.zig and the SSIMULACRA2 scor
 the CPU and are the caller's.
 """
 from . import _lib  # noqa: F401
-from .scorer import Ssimu2, Ssimu2Error, score_many, version  # noqa: F401
+from .scorer import Ssimu2, Ssimu2Error, query_device, score_many, version  # noqa: F401
 from . import tq  # noqa: F401
 
-__all__ = ["Ssimu2", "Ssimu2Error", "score_many", "version", "tq"]
+__all__ = ["Ssimu2", "Ssimu2Error", "query_device", "score_many", "version", "tq"]

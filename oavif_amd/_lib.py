@@ -31,7 +31,8 @@ TQ_MAX_PASS = 12
 BLUR_FIR, BLUR_RECURSIVE, BLUR_RECURSIVE_FMA = 0, 1, 2   # ssimu2_ctx_set_blur (include/ssimu2_hip.h)
 
 EXPORTED_SYMBOLS = (
-    "ssimu2_ctx_create", "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_ctx_set_blur",
+    "ssimu2_ctx_create", "ssimu2_query_device", "ssimu2_ctx_device_info", "ssimu2_host_alloc", "ssimu2_host_free",
+    "ssimu2_prefetch", "ssimu2_prefetch_join", "ssimu2_ctx_destroy", "ssimu2_ctx_set_blur",
     "ssimu2_last_error",
     "ssimu2_score_rgb8", "ssimu2_set_reference", "ssimu2_score_against_reference",
     "ssimu2_score_against_reference_strided", "ssimu2_set_reference_device",
@@ -75,6 +76,26 @@ class TQSpecOptions(ctypes.Structure):
 
     def __init__(self, max_fanout: int = 1, first_wave_fanout: int = 0):
         super().__init__(self.TAG | ctypes.sizeof(TQSpecOptions), int(max_fanout), int(first_wave_fanout))
+
+
+class DeviceInfo(ctypes.Structure):
+    """ssimu2_device_info (include/ssimu2_hip.h): what the library read off a HIP device."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("arch", ctypes.c_char * 64),
+                ("name", ctypes.c_char * 128), ("pci_bus_id", ctypes.c_char * 32), ("compute_units", ctypes.c_uint32),
+                ("lds_bytes_per_cu", ctypes.c_uint32), ("lds_bytes_per_workgroup", ctypes.c_uint32),
+                ("wavefront_size", ctypes.c_uint32), ("hbm_bytes", ctypes.c_uint64), ("numa_node", ctypes.c_int32),
+                ("usable", ctypes.c_int32)]
+
+    def __init__(self):
+        super().__init__()
+        self.struct_size = ctypes.sizeof(DeviceInfo)
+
+    def as_dict(self) -> dict:
+        return {"device": int(self.device), "arch": self.arch.decode(), "name": self.name.decode(),
+                "pci_bus_id": self.pci_bus_id.decode(), "compute_units": int(self.compute_units),
+                "lds_bytes_per_cu": int(self.lds_bytes_per_cu), "lds_bytes_per_workgroup": int(self.lds_bytes_per_workgroup),
+                "wavefront_size": int(self.wavefront_size), "hbm_bytes": int(self.hbm_bytes),
+                "numa_node": int(self.numa_node), "usable": bool(self.usable)}
 
 
 class TQSpecStats(ctypes.Structure):
@@ -138,6 +159,15 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
     L.ssimu2_ctx_create.restype = ci
     L.ssimu2_prefetch.argtypes = [ci]
     L.ssimu2_prefetch.restype = ci
+    if hasattr(L, "ssimu2_query_device"):   # absent from builds before v8 (scripts/gpu_ab.py loads those too)
+        L.ssimu2_query_device.argtypes = [ci, ctypes.POINTER(DeviceInfo)]
+        L.ssimu2_query_device.restype = ci
+        L.ssimu2_ctx_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
+        L.ssimu2_ctx_device_info.restype = ci
+        L.ssimu2_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.ssimu2_host_alloc.restype = ci
+        L.ssimu2_host_free.argtypes = [vp, vp]
+        L.ssimu2_host_free.restype = ci
     if hasattr(L, "ssimu2_prefetch_join"):
         L.ssimu2_prefetch_join.argtypes = [ci]
         L.ssimu2_prefetch_join.restype = ci

@@ -407,6 +407,10 @@ def parse_cli(argv=None):
                          "shard and on this rank's GPU (LOCAL_RANK is handed to the child), instead of searching in "
                          "this process: e.g. oavif_amd/lib/oavif_host, the compiled C host of this repository")
     ap.add_argument("--out-dir", default="temp_avif_output")
+    ap.add_argument("--collective-json", default=None, metavar="PATH",
+                    help="rank 0 writes the job's `collective` record (oavif_amd/collective.py: backend, world size, every "
+                         "rank's device / PCI bus id / NUMA node / pinned cores, library versions) and the run's totals "
+                         "(images, wall seconds, images per second) to PATH")
     args = ap.parse_args(argv)
     args.oavif_path = None
     if len(args.paths) == 2:
@@ -460,6 +464,13 @@ def main(argv=None) -> int:
     # is the rehearsal mode bench.py also has, for boxes with fewer GPUs than ranks (local_rank
     # modulo the device count).
     backend = os.environ.get("OAVIF_BENCH_BACKEND", "gloo" if ppg > 1 else "nccl")
+    from . import collective
+    if world > 1:
+        why = collective.preflight(backend, local_world)
+        if why:   # every rank of the host sees the same count and leaves with the same code
+            print(f"oavif_amd.batch: rank {rank}: refusing to run: {why}", file=sys.stderr)
+            return 4
+    launcher_local_rank = local_rank
     local_rank = local_rank // ppg
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -478,6 +489,22 @@ def main(argv=None) -> int:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+
+    # The process group's first job: every rank's description of itself, gathered over the backend the record
+    # gather will use.  Two RCCL ranks on one GPU, or a rank set that is not what the launcher announced, end the
+    # run here on every rank (all judge the same gathered records) instead of in a plausible summary.
+    coll_group = world > 1 or gather_always
+    coll, bad = collective.check_in(rank, launcher_local_rank, local_rank, backend, world, local_world,
+                                    tensor_device=torch.device("cuda", local_rank) if coll_group and backend == "nccl" else None,
+                                    pinned=pinned if want_pin else None, grouped=coll_group)
+    if ppg > 1:
+        coll["ranks_per_gpu"] = ppg
+    if bad:
+        if rank == 0:
+            print("oavif_amd.batch: refusing to run:\n  " + "\n  ".join(bad), file=sys.stderr)
+        if coll_group:
+            dist.destroy_process_group()
+        return 4
 
     files = list_images(args.images_dir)
     if not files:
@@ -534,6 +561,16 @@ def main(argv=None) -> int:
         print(f"Host cores per rank{'' if pinned else ' (' + pin_note + ')'}: " + "; ".join(
             f"rank {r}: {len(cs)} ({hostinfo.format_cpus(cs)})" for r, cs in enumerate(core_sets)))
         print(f"Worker threads per rank: {args.workers}; ranks per GPU: {ppg}; dealing: largest file first")
+        print(f"Collective: backend {coll['backend']}, world {coll['world_size']}, {coll['distinct_devices']} distinct device(s): "
+              + "; ".join(f"rank {r_.get('rank')} -> GPU {r_.get('device')} at {r_.get('pci_bus_id')} (NUMA {r_.get('numa_node')})"
+                          for r_ in coll["ranks"]))
+        if args.collective_json:
+            import json
+            ok_n = sum(1 for r_ in results if r_.status == "ok")
+            with open(args.collective_json, "w") as f:
+                json.dump({"collective": coll, "images": len(results), "images_ok": ok_n, "wall_s": round(wall, 3),
+                           "images_per_s": round(ok_n / wall, 3) if wall > 0 else None,
+                           "workers_per_rank": args.workers, "ranks_per_gpu": ppg}, f, indent=1)
         from . import cli
         depth, note = cli.codec_depth(cli.AvifEncOptions().tenbit, False)   # the batch runs the reference's defaults
         if note:

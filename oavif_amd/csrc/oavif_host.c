@@ -430,6 +430,10 @@ typedef struct {
     size_t buf_size;
     int buf_q;
     double encode_ms, decode_ms, score_ms;
+    /* decodeAvifCommon's RGB buffer (io.zig:452-482) in page-locked memory of the scorer (ssimu2_host_alloc), used by
+       every pass once the context exists: libavif converts straight into it and the upload is one DMA.  NULL = the
+       context is not up yet (the first pass's CPU half runs during HIP start-up), or OAVIF_HOST_PINNED=0. */
+    uint8_t* pinned;
 } EncCtx;
 
 #include <time.h>
@@ -505,13 +509,21 @@ done:
    8-bit RGB(A) rows) touches nothing shared but the read-only source image, so the probes of a speculative wave
    run it on threads and the FIRST pass of a run runs it while the scorer is still starting up; the GPU half
    scores those rows on a given context. */
-typedef struct { avifDecoderHead* dec; avifRGBImage rgb; } Decoded;
+typedef struct { avifDecoderHead* dec; avifRGBImage rgb; int caller_pixels; } Decoded;
 static void decoded_free(Decoded* d) {
-    if (d->rgb.pixels) av.RGBImageFreePixels(&d->rgb);
+    if (d->rgb.pixels && !d->caller_pixels) av.RGBImageFreePixels(&d->rgb);
     if (d->dec) av.DecoderDestroy(d->dec);
     memset(d, 0, sizeof *d);
 }
-static int pass_cpu(const EncCtx* e, uint32_t q, uint8_t** out_avif, size_t* out_size, Decoded* d, double times_ms[3]) {
+static uint8_t* pinned_frame(ssimu2_ctx* scorer, const Image* src) { /* room for RGBA rows; NULL = use libavif's own */
+    void* p = NULL;
+    const char* v = getenv("OAVIF_HOST_PINNED");
+    if (v && !strcmp(v, "0")) return NULL;
+    if (ssimu2_host_alloc(scorer, (size_t)src->w * src->h * 4, &p) != SSIMU2_OK) return NULL; /* not fatal */
+    return (uint8_t*)p;
+}
+static int pass_cpu(const EncCtx* e, uint32_t q, uint8_t** out_avif, size_t* out_size, Decoded* d, double times_ms[3],
+                    uint8_t* pinned) {
     uint8_t* avif = NULL;
     size_t avif_size = 0;
     memset(d, 0, sizeof *d);
@@ -530,7 +542,11 @@ static int pass_cpu(const EncCtx* e, uint32_t q, uint8_t** out_avif, size_t* out
     av.RGBImageSetDefaults(&d->rgb, img);
     d->rgb.depth = 8;                                        /* io.zig:470-471 */
     d->rgb.format = img->alphaPlane ? AVIF_RGBA : AVIF_RGB;  /* io.zig:473 */
-    if (av.RGBImageAllocatePixels(&d->rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
+    if (pinned) { /* the caller's buffer in place of avifRGBImageAllocatePixels: tight rows, as libavif would lay them */
+        d->rgb.pixels = pinned;
+        d->rgb.rowBytes = img->width * (d->rgb.format == AVIF_RGBA ? 4u : 3u);
+        d->caller_pixels = 1;
+    } else if (av.RGBImageAllocatePixels(&d->rgb) != AVIF_OK) { fail("AllocatePixelsFailed", NULL); goto done; }
     if ((r = av.ImageYUVToRGB(img, &d->rgb)) != AVIF_OK) { fail("ConvertToRGBFailed", av.ResultToString(r)); goto done; }
     times_ms[0] = t1 - t0; times_ms[1] = now_ms() - t1;
     *out_avif = avif; *out_size = avif_size;
@@ -560,6 +576,7 @@ static int ensure_scorer(EncCtx* e) { /* ssimu2_prefetch started this at process
     if ((rc = ssimu2_ctx_set_blur(e->scorer, e->blur)) || (rc = ssimu2_set_reference(e->scorer, e->rgb8, e->src->w, e->src->h)))
         return fail("ScorerFailed", ssimu2_last_error(e->scorer));
     phase("reference uploaded and cached");
+    e->pinned = pinned_frame(e->scorer, e->src);
     return 0;
 }
 
@@ -569,7 +586,7 @@ static int probe(void* user, uint32_t q, double* out_score) { /* the sequential 
     size_t n = 0;
     double t[3] = {0, 0, 0};
     Decoded d;
-    if (pass_cpu(e, q, &avif, &n, &d, t)) return -1;
+    if (pass_cpu(e, q, &avif, &n, &d, t, e->pinned)) return -1;
     if (e->scorer == NULL) phase("first probe encoded and decoded");
     if (ensure_scorer(e) || pass_score(e->scorer, &d, out_score, t)) { decoded_free(&d); free(avif); return -1; }
     e->encode_ms += t[0]; e->decode_ms += t[1]; e->score_ms += t[2];
@@ -589,6 +606,7 @@ typedef struct {
     uint32_t fan;
     ssimu2_ctx* ctx[OAVIF_TQ_MAX_FANOUT];
     int have_ref[OAVIF_TQ_MAX_FANOUT]; /* a context gets the reference when a wave first uses it */
+    uint8_t* pinned[OAVIF_TQ_MAX_FANOUT]; /* ... and its page-locked frame buffer (EncCtx.pinned) */
     struct { int q; uint8_t* b; size_t n; } kept[OAVIF_TQ_MAX_PASS * OAVIF_TQ_MAX_FANOUT]; /* every probe's bytes: any may be the answer */
     int nkept;
 } Spec;
@@ -605,11 +623,12 @@ static void* spec_job(void* arg) {
         }
         s->have_ref[j->slot] = 1;
     }
+    if (!s->pinned[j->slot]) s->pinned[j->slot] = j->slot == 0 && s->e->pinned ? s->e->pinned : pinned_frame(s->ctx[j->slot], s->e->src);
     uint8_t* avif = NULL;
     size_t n = 0;
     double t[3] = {0, 0, 0};
     Decoded d;
-    if (pass_cpu(s->e, j->q, &avif, &n, &d, t)) return NULL;
+    if (pass_cpu(s->e, j->q, &avif, &n, &d, t, s->pinned[j->slot])) return NULL;
     if (pass_score(s->ctx[j->slot], &d, &j->score, t)) { free(avif); return NULL; }
     pthread_mutex_lock(&g_lock);
     s->e->encode_ms += t[0]; s->e->decode_ms += t[1]; s->e->score_ms += t[2];
@@ -663,9 +682,15 @@ typedef struct { /* everything run() allocates, released on every path */
 
 static void run_free(Run* r) {
     for (uint32_t i = 1; i < OAVIF_TQ_MAX_FANOUT; ++i)
-        if (r->spec.ctx[i]) ssimu2_ctx_destroy(r->spec.ctx[i]);
+        if (r->spec.ctx[i]) {
+            ssimu2_host_free(r->spec.ctx[i], r->spec.pinned[i]);
+            ssimu2_ctx_destroy(r->spec.ctx[i]);
+        }
     for (int k = 0; k < r->spec.nkept; ++k) free(r->spec.kept[k].b);
-    if (r->e.scorer) ssimu2_ctx_destroy(r->e.scorer);
+    if (r->e.scorer) {
+        ssimu2_host_free(r->e.scorer, r->e.pinned ? r->e.pinned : r->spec.pinned[0]);
+        ssimu2_ctx_destroy(r->e.scorer);
+    }
     if (r->e.image) av.ImageDestroy(r->e.image);
     free(r->e.buf);
     free(r->once);

@@ -10,17 +10,18 @@
 //   lin pyramid : scales 1..5 of both frames, planar fp32 linear RGB [3][h_s][w_s]
 //                 (scale 0 is read straight from the u8 frames through the sRGB LUT)
 //   partials    : fp64 [scale][18 stats][workgroups] partial sums
-//   result      : fp64 [108 averages][score][nscales], mirrored in pinned host memory
+//   result      : fp64 [108 averages][score][nscales], written by k_finalize straight into pinned host memory
 //
 //   SSIMU2_BLUR_RECURSIVE modes only (ssimu2_recursive.h), every scale packed: XYB planes of both
 //   frames, the reference's cached blur(x) / blur(x*x) planes, the horizontal pass of a pass's planes
 //
 // One score = ONE k_pyramid_bands launch (all five levels), ONE k_march launch covering all six scales, one
-// k_finalize launch, one 880-byte D2H copy (recursive modes: conversion, horizontal pass, vertical
-// pass + maps, k_finalize); everything on the ctx stream, no host sync inside (enqueue / wait
+// k_finalize launch that writes its 880 bytes into the host mirror itself (recursive modes: conversion, horizontal
+// pass, vertical pass + maps, k_finalize); everything on the ctx stream, no host sync inside (enqueue / wait
 // split).  Streams the library creates are placed on distinct hardware queues ("stream placement").
 #include <hip/hip_runtime.h>
 
+#include <ctype.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -40,6 +41,8 @@
 using namespace ssimu2;
 
 namespace {
+
+constexpr uint32_t kMinLdsPerCu = 160u * 1024u;  // gfx950's; what ssimu2_ctx_create requires (include/ssimu2_hip.h)
 
 const double kWeightsHost[108] = {
     0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0,
@@ -160,11 +163,13 @@ struct ssimu2_ctx {
     double* d_rg_part = nullptr;  // [scale][18][column groups]
     unsigned* d_rg_q = nullptr;   // job cursors of the persistent recursive-mode kernels (4 words)
     int num_cus = 0;              // workgroups of those kernels: one per CU
+    ssimu2_device_info dev{};     // what ctx_create saw of the device (and checked: gfx950, 160 KB of LDS per CU)
+    unsigned rg_v_pad = 0;        // unused dynamic LDS of k_rg_v's launch: rg_v_pad_bytes(dev.lds_bytes_per_cu)
     size_t cap_rg_part = 0;       // doubles
     float* d_rg_dbg = nullptr;    // instrumented builds: 15 + 15 raw planes of scale rg_dbg_scale
     size_t cap_rg_dbg = 0;
-    double* d_result = nullptr;   // 110 doubles
-    double* h_result = nullptr;   // pinned mirror
+    double* d_result = nullptr;   // 110 doubles in device memory: the stage timing of the instrumented build only
+    double* h_result = nullptr;   // page-locked host memory k_finalize writes the result into (110 doubles)
 
     // reference state
     bool have_ref = false;
@@ -428,9 +433,7 @@ int rg_ensure(ssimu2_ctx* c, const Pyramid& p) {
     }
     if (!c->d_rg_q) {
         HIP_TRY(c, hipMalloc(&c->d_rg_q, 4 * sizeof(unsigned)));
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
-        c->num_cus = cus;
+        c->num_cus = c->dev.compute_units > 0 ? (int)c->dev.compute_units : 256;
     }
     if (c->rg_dbg_scale >= 0 && c->rg_dbg_scale < p.nscales) {
         const size_t nd = (size_t)24 * rg_pitch(p.w[c->rg_dbg_scale]) * p.h[c->rg_dbg_scale] + 16;  // 15 h planes + 9 v planes
@@ -559,20 +562,6 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
     int hblocks, vblocks;
     rg_build_plan(c, p, false, &rp, &hblocks, &vblocks);
     const bool fma = c->blur_mode == SSIMU2_BLUR_RECURSIVE_FMA, dbg = rg_debugging(c, p);
-    if (p.nscales > 0) {  // a frame below 8 x 8 has no scale to score
-        rg_launch_convert(c, p, d_dist, rp);
-        const int vgrid = vblocks < c->num_cus ? vblocks : c->num_cus;
-        rg_launch_h<false>(c, fma, hblocks, rp);
-        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vgrid), dim3(512), RG_V_PAD_BYTES, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vgrid), dim3(512), RG_V_PAD_BYTES, c->stream, rp);
-        if (dbg) {
-            rg_debug_keep_h(c, p, rp, false);
-            const int s = c->rg_dbg_scale;
-            rp.emit[s] = c->d_rg_dbg + (size_t)15 * rg_pitch(p.w[s]) * p.h[s];  // [channel][{y, yy, xy}][n]
-            if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
-            else hipLaunchKernelGGL((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
-        }
-    }
     FinalizeArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.nscales = p.nscales;
@@ -581,9 +570,23 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
         fa.nblocks[s] = rp.vgroups[s];
         fa.inv_pixels[s] = 1.0 / ((double)p.w[s] * (double)p.h[s]);
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
+    if (p.nscales > 0) {  // a frame below 8 x 8 has no scale to score
+        rg_launch_convert(c, p, d_dist, rp);
+        const int vgrid = vblocks < c->num_cus ? vblocks : c->num_cus;
+
+        rg_launch_h<false>(c, fma, hblocks, rp);
+        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
+        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
+        if (dbg) {
+            rg_debug_keep_h(c, p, rp, false);
+            const int s = c->rg_dbg_scale;
+            rp.emit[s] = c->d_rg_dbg + (size_t)15 * rg_pitch(p.w[s]) * p.h[s];  // [channel][{y, yy, xy}][n]
+            if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
+            else hipLaunchKernelGGL((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);  // result: see enqueue_score
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, 110 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     c->pending = true;
     return SSIMU2_OK;
 }
@@ -627,10 +630,9 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
         else
             hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->d_result);
+    // the 880-byte result goes straight into the context's page-locked mirror: no D2H copy command per score
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, 110 * sizeof(double),
-                              hipMemcpyDeviceToHost, c->stream));
     c->pending = true;
     return SSIMU2_OK;
 }
@@ -648,7 +650,7 @@ int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t
 
 extern "C" {
 
-const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v7 (pair ring, b64 taps, dword pixel loads; recursive blur: cached reference, 3 lanes per line, persistent vertical pass; placed streams; sized option structs)"; }
+const char* ssimu2_version(void) { return "oavif_amd ssimu2 gfx950 v8 (pair ring, b64 taps, dword pixel loads; recursive blur: cached reference, 3 lanes per line, persistent vertical pass; placed streams; tagged option structs; device check at context creation; pinned host buffers)"; }
 
 int ssimu2_ctx_set_blur(ssimu2_ctx* c, int mode) {
     if (!c) return SSIMU2_ERR_INVALID_ARG;
@@ -843,20 +845,150 @@ int ssimu2_ctx_create(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     return ctx_create_impl(device, hip_stream, out_ctx);
 }
 
-static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
-    if (!out_ctx) return SSIMU2_ERR_INVALID_ARG;
-    *out_ctx = nullptr;
+// What the runtime and sysfs say of HIP device `device`; `why` (optional) receives the reason when the device is not
+// one this library can run on.  No context, no allocation; hipGetDeviceProperties initialises the runtime.
+static int query_device_impl(int device, ssimu2_device_info* d, std::string* why) {
+    static std::mutex mu;                      // contexts are created from worker threads: one record per device,
+    static ssimu2_device_info accepted[64];    // read from the runtime and sysfs once
+    static bool have[64] = {false};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < 64 && have[device]) {
+        *d = accepted[device];
+        return SSIMU2_OK;
+    }
+    memset(d, 0, sizeof *d);
+    d->struct_size = (uint32_t)sizeof *d;
+    d->device = device;
+    d->numa_node = -1;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
-        g_create_error = "no usable HIP device (hipGetDeviceCount: ";
-        g_create_error += hipGetErrorString(e);
-        g_create_error += ")";
+        if (why) *why = std::string("no usable HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) + ", " +
+                        std::to_string(ndev) + " device(s), index " + std::to_string(device) + ")";
         return SSIMU2_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t pr;
+    if ((e = hipGetDeviceProperties(&pr, device)) != hipSuccess) {
+        if (why) *why = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return SSIMU2_ERR_HIP;
+    }
+    snprintf(d->arch, sizeof d->arch, "%s", pr.gcnArchName);
+    snprintf(d->name, sizeof d->name, "%s", pr.name);
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess)
+        snprintf(bus, sizeof bus, "%04x:%02x:%02x.0", pr.pciDomainID, pr.pciBusID, pr.pciDeviceID);
+    for (char* q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    snprintf(d->pci_bus_id, sizeof d->pci_bus_id, "%s", bus);
+    d->compute_units = pr.multiProcessorCount > 0 ? (uint32_t)pr.multiProcessorCount : 0;
+    // LDS of one CU: the runtime reports it as maxSharedMemoryPerMultiProcessor; the per-workgroup limit
+    // (sharedMemPerBlock) is the same number on gfx950 (a workgroup may take the whole 160 KB)
+    d->lds_bytes_per_workgroup = (uint32_t)pr.sharedMemPerBlock;
+    size_t per_cu = pr.maxSharedMemoryPerMultiProcessor;
+    int attr = 0;
+    if (hipDeviceGetAttribute(&attr, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && attr > 0 &&
+        (size_t)attr > per_cu)
+        per_cu = (size_t)attr;
+    if (pr.sharedMemPerBlock > per_cu) per_cu = pr.sharedMemPerBlock;  // a workgroup's limit cannot exceed its CU's LDS
+    d->lds_bytes_per_cu = (uint32_t)per_cu;
+    d->wavefront_size = pr.warpSize > 0 ? (uint32_t)pr.warpSize : 0;
+    d->hbm_bytes = (uint64_t)pr.totalGlobalMem;
+    {
+        char path[128];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", d->pci_bus_id);
+        if (FILE* f = fopen(path, "r")) {
+            int node = -1;
+            if (fscanf(f, "%d", &node) == 1) d->numa_node = node;
+            fclose(f);
+        }
+    }
+    (void)hipGetLastError();
+    if (strncmp(d->arch, "gfx950", 6) != 0) {
+        if (why) *why = std::string("device ") + std::to_string(device) + " is " + d->arch +
+                        ", not gfx950: this library holds gfx950 (MI355X) code only";
+        return SSIMU2_ERR_NO_DEVICE;
+    }
+    if (d->lds_bytes_per_cu < kMinLdsPerCu) {
+        if (why) *why = std::string("device ") + std::to_string(device) + " (" + d->arch + ") reports " +
+                        std::to_string(d->lds_bytes_per_cu) + " bytes of LDS per compute unit, LDS < 160 KB";
+        return SSIMU2_ERR_NO_DEVICE;
+    }
+    if (d->wavefront_size != 64) {
+        if (why) *why = std::string("device ") + std::to_string(device) + " runs wavefronts of " +
+                        std::to_string(d->wavefront_size) + " lanes, the kernels are written for 64";
+        return SSIMU2_ERR_NO_DEVICE;
+    }
+    d->usable = 1;
+    if (device < 64) {
+        accepted[device] = *d;
+        have[device] = true;
+    }
+    return SSIMU2_OK;
+}
+
+int ssimu2_query_device(int device, ssimu2_device_info* out) {
+    if (!out || out->struct_size != sizeof(ssimu2_device_info)) return SSIMU2_ERR_INVALID_ARG;
+    ssimu2_device_info d;
+    std::string why;
+    const int rc = query_device_impl(device, &d, &why);
+    if (rc == SSIMU2_ERR_NO_DEVICE && d.arch[0] == 0) {  // no such device at all
+        g_create_error = why;
+        return rc;
+    }
+    if (rc == SSIMU2_ERR_HIP) {
+        g_create_error = why;
+        return rc;
+    }
+    *out = d;  // a device of another kind is described too, with usable = 0
+    return SSIMU2_OK;
+}
+
+int ssimu2_ctx_device_info(const ssimu2_ctx* c, ssimu2_device_info* out) {
+    if (!c || !out || out->struct_size != sizeof(ssimu2_device_info)) return SSIMU2_ERR_INVALID_ARG;
+    *out = c->dev;
+    return SSIMU2_OK;
+}
+
+int ssimu2_host_alloc(ssimu2_ctx* c, size_t bytes, void** out_ptr) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!out_ptr || bytes == 0) return c->fail(SSIMU2_ERR_INVALID_ARG, "ssimu2_host_alloc: null out_ptr or zero bytes");
+    *out_ptr = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const hipError_t e = hipHostMalloc(out_ptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        *out_ptr = nullptr;
+        (void)hipGetLastError();
+        return c->fail(SSIMU2_ERR_OOM, "hipHostMalloc(pinned frame buffer)", e);
+    }
+    return SSIMU2_OK;
+}
+
+int ssimu2_host_free(ssimu2_ctx* c, void* ptr) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!ptr) return SSIMU2_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipHostFree(ptr));
+    return SSIMU2_OK;
+}
+
+static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
+    if (!out_ctx) return SSIMU2_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    // capability check first (include/ssimu2_hip.h, SSIMU2_ERR_NO_DEVICE): a device index that exists, gfx950,
+    // 160 KB of LDS per CU -- instead of a failure at the first launch on anything else
+    ssimu2_device_info info;
+    {
+        std::string why;
+        const int rc = query_device_impl(device, &info, &why);
+        if (rc != SSIMU2_OK) {
+            g_create_error = why;
+            return rc;
+        }
     }
     ssimu2_ctx* c = new (std::nothrow) ssimu2_ctx();
     if (!c) return SSIMU2_ERR_OOM;
     c->device = device;
+    c->dev = info;
+    c->rg_v_pad = rg_v_pad_bytes(info.lds_bytes_per_cu);
 #define CREATE_TRY(call)                                                        \
     do {                                                                        \
         hipError_t e2 = (call);                                                 \
@@ -878,6 +1010,7 @@ static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     CREATE_TRY(hipEventCreate(&c->ev0));
     CREATE_TRY(hipEventCreate(&c->ev1));
     CREATE_TRY(hipMalloc(&c->d_result, 110 * sizeof(double)));
+
     CREATE_TRY(hipHostMalloc(&c->h_result, 110 * sizeof(double), hipHostMallocDefault));
     {
         // The constant table lives in device memory of this module, one copy per device, shared

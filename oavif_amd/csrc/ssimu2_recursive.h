@@ -620,12 +620,21 @@ __global__ __launch_bounds__(64 * NK) void k_rg_v_emit(RgPlan p) {
 // Vertical pass of a pass's planes + maps.  Waves 0-2 recurse {y, y*y, x*y} into a double-buffered
 // LDS tile of ten rows, waves 3-7 turn two of those rows each, with the cached mu1 / s11 and the two
 // frames' XYB values, into the six sums.  A JOB is one channel of 64 columns of one scale (a chain of
-// h steps); round 4: PERSISTENT like k_rg_h -- one workgroup per CU (launched with RG_V_PAD_BYTES
+// h steps); round 4: PERSISTENT like k_rg_h -- one workgroup per CU (launched with rg_v_pad_bytes()
 // of unused dynamic LDS, past half a CU's), the jobs of all scales handed out longest first through a cursor.  Measured before the change
 // (profiles/r04_rg_chain_vs_bytes.log): capping the round-3 launch at one workgroup per CU took it from
 // 193 to 170 us -- with two per CU the dispatcher doubles up full-resolution column groups on some CUs
 // while others run the small scales, and a CU with two of them issues at half the rate per chain.
-constexpr int RG_V_PAD_BYTES = 70 * 1024;  // dynamic LDS of the launch, never touched: pushes the workgroup past 80 KB
+// Dynamic LDS of the launch, never touched: with the kernel's own tiles it pushes the workgroup past half of the CU's
+// LDS, so the hardware cannot place a second workgroup on the CU.  Derived from the LDS size ssimu2_ctx_create read
+// off the device (160 KB on gfx950: 81 KB - 15 KB of tiles = 66 KB); a device with less than 160 KB never gets here
+// (SSIMU2_ERR_NO_DEVICE at context creation).
+constexpr unsigned RG_V_STATIC_LDS = 2u * 3u * RG_VB * RG_VW * (unsigned)sizeof(float);  // s_out; the rest is < 1 KB
+constexpr unsigned rg_v_pad_bytes(unsigned lds_bytes_per_cu) {
+    return lds_bytes_per_cu / 2u + 1024u > RG_V_STATIC_LDS ? lds_bytes_per_cu / 2u + 1024u - RG_V_STATIC_LDS : 0u;
+}
+static_assert(rg_v_pad_bytes(160u * 1024u) + RG_V_STATIC_LDS > 80u * 1024u && rg_v_pad_bytes(160u * 1024u) + RG_V_STATIC_LDS + 1024u <= 160u * 1024u,
+              "k_rg_v: one workgroup per 160 KB CU, and the request fits");
 
 template <bool FMA>
 __global__ __launch_bounds__(512) void k_rg_v(RgPlan p) {

@@ -31,6 +31,17 @@ def _check_rgb8(a, name: str) -> np.ndarray:
     return a
 
 
+def query_device(device: int = 0, instrumented: bool = False) -> dict:
+    """ssimu2_query_device: what the library reads off HIP device `device` without creating a context
+    (`usable` False = ssimu2_ctx_create would refuse it: not gfx950, or less than 160 KB of LDS per CU)."""
+    L = _lib.instr_lib() if instrumented else _lib.lib()
+    d = _lib.DeviceInfo()
+    rc = L.ssimu2_query_device(int(device), ctypes.byref(d))
+    if rc != 0:
+        raise Ssimu2Error(rc, L.ssimu2_last_error(None).decode() or "ssimu2_query_device failed")
+    return d.as_dict()
+
+
 class Ssimu2:
     """One scorer context = one HIP stream + device scratch (not re-entrant)."""
 
@@ -55,8 +66,42 @@ class Ssimu2:
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) and self._ctx.value:
+            for ptr in list(getattr(self, "_pinned", {}).values()):
+                self._L.ssimu2_host_free(self._ctx, ctypes.c_void_p(ptr))
+            self._pinned = {}
             self._L.ssimu2_ctx_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
+
+    def device_info(self) -> dict:
+        """ssimu2_ctx_device_info: the record the context was created with (arch, LDS per CU, PCI bus id, ...)."""
+        d = _lib.DeviceInfo()
+        rc = self._L.ssimu2_ctx_device_info(self._ctx, ctypes.byref(d))
+        if rc != 0:
+            self._raise(rc)
+        return d.as_dict()
+
+    def host_alloc(self, shape) -> np.ndarray:
+        """ssimu2_host_alloc: a uint8 array of `shape` in page-locked host memory (uploads from it skip the HIP
+        runtime's staging copy).  Freed by host_free or when the context closes; do not use it afterwards."""
+        shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
+        n = int(np.prod(shape))
+        ptr = ctypes.c_void_p()
+        rc = self._L.ssimu2_host_alloc(self._ctx, n, ctypes.byref(ptr))
+        if rc != 0:
+            self._raise(rc)
+        a = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr.value)).reshape(shape)
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        self._pinned[a.ctypes.data] = ptr.value
+        return a
+
+    def host_free(self, a: np.ndarray) -> None:
+        ptr = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if ptr is None:
+            raise ValueError("not a buffer of this context's host_alloc")
+        rc = self._L.ssimu2_host_free(self._ctx, ctypes.c_void_p(ptr))
+        if rc != 0:
+            self._raise(rc)
 
     def __del__(self):
         try:

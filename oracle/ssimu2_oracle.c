@@ -68,6 +68,40 @@
 #define OR_BLUR_EXACT 2 /* the same 9-tap operator accumulated in fp64, result rounded to fp32:
                           what both fp32 forms approximate (evidence for DESIGN.md 2.1) */
 
+/* ---- stage variants (the pin kit: tests/golden/pin_kit, scripts/pin_blur_mode.py) -------------
+ * fssimu2's source is not available, so WHERE it might differ from the published algorithm is not
+ * known either.  Besides the blur's evaluation order (the modes above), these bits switch single
+ * stages to the cheap, plausible alternatives a re-implementation could have taken; every one is
+ * OFF in the oracle proper (or_compute_ssimu2) and none has a counterpart in the HIP kernels.  A
+ * maintainer who can run fssimu2 scores the kit's pairs once and scripts/pin_blur_mode.py names the
+ * nearest variant -- i.e. the STAGE that differs -- instead of "no mode matches".
+ *   blur      EDGE_CLAMP / EDGE_MIRROR  samples outside the plane replicate the edge / mirror about
+ *                                       it instead of being zero (FIR family only)
+ *             GAUSS9 / GAUSS11          a true sampled sigma-1.5 Gaussian truncated at radius 4 / 5 and
+ *                                       normalised, in place of the recursion's impulse response
+ *   pyramid   DOWNSAMPLE_XYB            scale s+1 = 2x2 average of scale s's XYB planes (not of linear
+ *                                       light, re-converted)
+ *             DOWNSAMPLE_FLOOR          odd sizes drop the last row / column (floor(w/2)) instead of
+ *                                       replicating it (ceil(w/2))
+ *             SIZE_TEST_AFTER           a scale is scored only if ITS size is >= 8 (the published loop
+ *                                       tests the size before downsampling)
+ *   colour    SRGB_POWF                 the transfer function in fp32 (powf) instead of a table from fp64
+ *             CBRT_LIBM                 libm's cbrtf instead of or_cbrtf
+ *   maps      SUMS_F32                  the per-plane sums accumulated in fp32
+ * The generic convolution the blur variants use multiplies first and blurs then (published order). */
+#define OR_VAR_EDGE_CLAMP 0x1u
+#define OR_VAR_EDGE_MIRROR 0x2u
+#define OR_VAR_GAUSS9 0x4u
+#define OR_VAR_GAUSS11 0x8u
+#define OR_VAR_DOWNSAMPLE_XYB 0x10u
+#define OR_VAR_DOWNSAMPLE_FLOOR 0x20u
+#define OR_VAR_SIZE_TEST_AFTER 0x40u
+#define OR_VAR_SRGB_POWF 0x80u
+#define OR_VAR_CBRT_LIBM 0x100u
+#define OR_VAR_SUMS_F32 0x200u
+#define OR_VAR_BLUR_MASK (OR_VAR_EDGE_CLAMP | OR_VAR_EDGE_MIRROR | OR_VAR_GAUSS9 | OR_VAR_GAUSS11)
+#define OR_VAR_ALL 0x3FFu
+
 /* ---- constants of the published algorithm ------------------------------------- */
 
 static const float kC2 = 0.0009f;
@@ -368,6 +402,56 @@ static void blur_plane_prod(const or_gauss* rg, int mode, const float* a, const 
     fir_columns(rg, tmp, w, h, out);
 }
 
+/* ---- blur variants: a plain fp32 convolution with selectable taps and edge rule ----------------- */
+typedef struct {
+    int radius;     /* taps -radius..radius, symmetric */
+    float tap[8];   /* tap[d], d = 0..radius */
+    int edge;       /* 0 zero, 1 clamp, 2 mirror (about the edge sample: -1 -> 1) */
+} or_conv;
+
+static void conv_setup(const or_gauss* rg, unsigned variant, or_conv* cv) {
+    memset(cv, 0, sizeof *cv);
+    cv->edge = (variant & OR_VAR_EDGE_CLAMP) ? 1 : (variant & OR_VAR_EDGE_MIRROR) ? 2 : 0;
+    if (variant & (OR_VAR_GAUSS9 | OR_VAR_GAUSS11)) {
+        cv->radius = (variant & OR_VAR_GAUSS11) ? 5 : 4;
+        double t[8], sum = 0.0;
+        for (int d = 0; d <= cv->radius; ++d) {
+            t[d] = exp(-(double)(d * d) / (2.0 * 1.5 * 1.5));
+            sum += d ? 2.0 * t[d] : t[d];
+        }
+        for (int d = 0; d <= cv->radius; ++d) cv->tap[d] = (float)(t[d] / sum);
+    } else {
+        cv->radius = 4;
+        for (int d = 0; d <= 4; ++d) cv->tap[d] = rg->fir[d];
+    }
+}
+
+static inline float conv_at(const float* in, ptrdiff_t i, ptrdiff_t n, ptrdiff_t stride, int edge) {
+    if (i >= 0 && i < n) return in[i * stride];
+    if (edge == 0) return 0.0f;
+    if (edge == 1) return in[(i < 0 ? 0 : n - 1) * stride];
+    if (n == 1) return in[0];
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i; /* mirror without repeating the edge sample */
+    return in[i * stride];
+}
+
+static void conv_line(const or_conv* cv, const float* in, ptrdiff_t n, ptrdiff_t stride_in, float* out,
+                      ptrdiff_t stride_out) {
+    for (ptrdiff_t i = 0; i < n; ++i) {
+        float acc = cv->tap[0] * conv_at(in, i, n, stride_in, cv->edge);
+        for (int d = 1; d <= cv->radius; ++d)
+            acc = fmaf(cv->tap[d], conv_at(in, i - d, n, stride_in, cv->edge) + conv_at(in, i + d, n, stride_in, cv->edge), acc);
+        out[i * stride_out] = acc;
+    }
+}
+
+static void conv_plane(const or_conv* cv, const float* in, size_t w, size_t h, float* tmp, float* out) {
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t y = 0; y < (ptrdiff_t)h; ++y) conv_line(cv, in + y * w, (ptrdiff_t)w, 1, tmp + y * w, 1);
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t x = 0; x < (ptrdiff_t)w; ++x) conv_line(cv, tmp + x, (ptrdiff_t)h, (ptrdiff_t)w, out + x, (ptrdiff_t)w);
+}
+
 /* exported for tests: blur one plane */
 void or_blur_plane(const float* in, uint32_t w, uint32_t h, int mode, float* out) {
     or_gauss rg;
@@ -400,10 +484,15 @@ void or_srgb_lut(float* lut256) {
     }
 }
 
-/* interleaved RGB8 -> three linear planes */
-static void rgb8_to_linear(const uint8_t* rgb, size_t n, float* lin /* 3*n */) {
+/* interleaved RGB8 -> three linear planes (`fp32_pow`: OR_VAR_SRGB_POWF, the curve evaluated in fp32) */
+static void rgb8_to_linear(const uint8_t* rgb, size_t n, float* lin /* 3*n */, int fp32_pow) {
     float lut[256];
     or_srgb_lut(lut);
+    if (fp32_pow)
+        for (int i = 0; i < 256; ++i) {
+            const float v = (float)i / 255.0f;
+            lut[i] = v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f);
+        }
 #pragma omp parallel for schedule(static)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
         lin[i] = lut[rgb[3 * i]];
@@ -444,8 +533,10 @@ float or_cbrtf(float x) {
 
 /* linear RGB planes -> "positive XYB" planes (ToXYB then MakePositiveXYB).  Operation
    order (which products are fused) is fixed here and mirrored by the HIP kernels. */
-void or_linear_to_xyb(const float* lin, size_t n, float* xyb) {
-    const float cb = or_cbrtf(kOpsinBias);
+static void linear_to_xyb_impl(const float* lin, size_t n, float* xyb, int libm);
+void or_linear_to_xyb(const float* lin, size_t n, float* xyb) { linear_to_xyb_impl(lin, n, xyb, 0); }
+static void linear_to_xyb_impl(const float* lin, size_t n, float* xyb, int libm) {
+    const float cb = libm ? cbrtf(kOpsinBias) : or_cbrtf(kOpsinBias);
 #pragma omp parallel for schedule(static)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i) {
         const float r = lin[i], g = lin[n + i], b = lin[2 * n + i];
@@ -455,9 +546,9 @@ void or_linear_to_xyb(const float* lin, size_t n, float* xyb) {
         l = l < 0.0f ? 0.0f : l;
         m = m < 0.0f ? 0.0f : m;
         s = s < 0.0f ? 0.0f : s;
-        l = or_cbrtf(l) - cb;
-        m = or_cbrtf(m) - cb;
-        s = or_cbrtf(s) - cb;
+        l = (libm ? cbrtf(l) : or_cbrtf(l)) - cb; /* libm: OR_VAR_CBRT_LIBM */
+        m = (libm ? cbrtf(m) : or_cbrtf(m)) - cb;
+        s = (libm ? cbrtf(s) : or_cbrtf(s)) - cb;
         const float X = 0.5f * (l - m), Y = 0.5f * (l + m), B = s;
         xyb[2 * n + i] = (B - Y) + 0.55f;
         xyb[i] = fmaf(X, 14.0f, 0.42f);
@@ -466,8 +557,11 @@ void or_linear_to_xyb(const float* lin, size_t n, float* xyb) {
 }
 
 /* 2x2 box average of linear planes, edge pixels replicated (Downsample(in,2,2)) */
-void or_downsample2(const float* in, size_t w, size_t h, float* out) {
-    const size_t ow = (w + 1) / 2, oh = (h + 1) / 2;
+static void downsample2_impl(const float* in, size_t w, size_t h, float* out, int floor_dims);
+void or_downsample2(const float* in, size_t w, size_t h, float* out) { downsample2_impl(in, w, h, out, 0); }
+/* `floor_dims`: OR_VAR_DOWNSAMPLE_FLOOR, an odd last row / column is dropped instead of replicated */
+static void downsample2_impl(const float* in, size_t w, size_t h, float* out, int floor_dims) {
+    const size_t ow = floor_dims && w > 1 ? w / 2 : (w + 1) / 2, oh = floor_dims && h > 1 ? h / 2 : (h + 1) / 2;
     for (int c = 0; c < 3; ++c) {
         const float* pin = in + (size_t)c * w * h;
         float* pout = out + (size_t)c * ow * oh;
@@ -543,6 +637,40 @@ static void edge_diff_map(const float* img1, const float* mu1, const float* img2
     }
 }
 
+/* OR_VAR_SUMS_F32: both maps and their running sums in fp32, pixel order, one thread (deterministic) */
+static void maps_f32(const float* img1, const float* mu1, const float* img2, const float* mu2, const float* s11,
+                     const float* s22, const float* s12, size_t n, double* plane_avg /* 18 */) {
+    const float inv = 1.0f / (float)n;
+    for (int c = 0; c < 3; ++c) {
+        float sum0 = 0.f, sum1 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+        const float *a = mu1 + c * n, *b = mu2 + c * n, *p11 = s11 + c * n, *p22 = s22 + c * n, *p12 = s12 + c * n;
+        const float *r1 = img1 + c * n, *r2 = img2 + c * n;
+        for (size_t i = 0; i < n; ++i) {
+            const float m1 = a[i], m2 = b[i];
+            const float dm = m1 - m2;
+            const float num_m = 1.0f - dm * dm;
+            const float num_s = 2.0f * (p12[i] - m1 * m2) + kC2;
+            const float denom_s = (p11[i] - m1 * m1) + (p22[i] - m2 * m2) + kC2;
+            float d = 1.0f - (num_m * num_s) / denom_s;
+            d = d > 0.0f ? d : 0.0f;
+            sum0 += d;
+            sum1 += (d * d) * (d * d);
+            const float d1 = (1.0f + fabsf(r2[i] - m2)) / (1.0f + fabsf(r1[i] - m1)) - 1.0f;
+            const float art = d1 > 0.0f ? d1 : 0.0f, det = d1 < 0.0f ? -d1 : 0.0f;
+            e0 += art;
+            e1 += (art * art) * (art * art);
+            e2 += det;
+            e3 += (det * det) * (det * det);
+        }
+        plane_avg[c * 2] = (double)(inv * sum0);
+        plane_avg[c * 2 + 1] = (double)sqrtf(sqrtf(inv * sum1));
+        plane_avg[6 + c * 4] = (double)(inv * e0);
+        plane_avg[6 + c * 4 + 1] = (double)sqrtf(sqrtf(inv * e1));
+        plane_avg[6 + c * 4 + 2] = (double)(inv * e2);
+        plane_avg[6 + c * 4 + 3] = (double)sqrtf(sqrtf(inv * e3));
+    }
+}
+
 /* 108 averages -> score.  avg layout: [scale][18] = 6 ssim (c*2+n) then 12 edge (c*4+k). */
 double or_score_from_averages(const double* avg /* nscales*18 */, int nscales) {
     /* The published Score() walks `for c: for scale < scales.size(): for n` with a
@@ -603,9 +731,28 @@ void or_weights(double* out108) { memcpy(out108, kWeights, sizeof(kWeights)); }
 /* ---- the entry point: same contract as the call at tq.zig:37 ---------------------- */
 /* returns 0 on success; *out_score is the SSIMULACRA2 score; avg_out (optional) gets
    6*18 doubles (unused scales zero), nscales_out (optional) the scales evaluated. */
+static int compute_core(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h, uint32_t channels,
+                        int blur_mode, unsigned variant, double* out_score, double* avg_out, int* nscales_out);
+
 int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h,
                       uint32_t channels, int blur_mode, double* out_score, double* avg_out,
                       int* nscales_out) {
+    return compute_core(ref, dist, w, h, channels, blur_mode, 0u, out_score, avg_out, nscales_out);
+}
+
+/* The pin kit's entry point: the score with the stages named in `variant` (OR_VAR_* bits) switched to their
+   alternatives.  variant = 0 is or_compute_ssimu2.  Blur variants need an FIR-family `blur_mode` (-5 otherwise). */
+int or_compute_ssimu2_variant(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h, int blur_mode,
+                              unsigned variant, double* out_score, double* avg_out, int* nscales_out) {
+    if (variant & ~OR_VAR_ALL) return -5;
+    if ((variant & OR_VAR_BLUR_MASK) && blur_mode != OR_BLUR_FIR && blur_mode != OR_BLUR_FIR_PRODFIRST) return -5;
+    if ((variant & OR_VAR_EDGE_CLAMP) && (variant & OR_VAR_EDGE_MIRROR)) return -5;
+    if ((variant & OR_VAR_GAUSS9) && (variant & OR_VAR_GAUSS11)) return -5;
+    return compute_core(ref, dist, w, h, 3, blur_mode, variant, out_score, avg_out, nscales_out);
+}
+
+static int compute_core(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h, uint32_t channels,
+                        int blur_mode, unsigned variant, double* out_score, double* avg_out, int* nscales_out) {
     if (!ref || !dist || !out_score) return -1;
     if (channels != 3) return -2;
     if (w == 0 || h == 0) return -3;
@@ -630,8 +777,11 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
         free(s12); free(mu1); free(mu2); free(tmp); free(dtmp);
         return -4;
     }
-    rgb8_to_linear(ref, n, lin1);
-    rgb8_to_linear(dist, n, lin2);
+    rgb8_to_linear(ref, n, lin1, (variant & OR_VAR_SRGB_POWF) != 0);
+    rgb8_to_linear(dist, n, lin2, (variant & OR_VAR_SRGB_POWF) != 0);
+    or_conv cv;
+    conv_setup(&rg, variant, &cv);
+    const int libm_cbrt = (variant & OR_VAR_CBRT_LIBM) != 0, floor_dims = (variant & OR_VAR_DOWNSAMPLE_FLOOR) != 0;
 
     double avg[OR_NUM_SCALES * 18];
     memset(avg, 0, sizeof(avg));
@@ -640,22 +790,43 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
     for (int scale = 0; scale < OR_NUM_SCALES; ++scale) {
         if (cw < 8 || ch < 8) break;
         if (scale) {
-            const size_t ow = (cw + 1) / 2, oh = (ch + 1) / 2;
-            or_downsample2(lin1, cw, ch, dtmp);
-            memcpy(lin1, dtmp, sizeof(float) * 3 * ow * oh);
-            or_downsample2(lin2, cw, ch, dtmp);
-            memcpy(lin2, dtmp, sizeof(float) * 3 * ow * oh);
+            const size_t ow = floor_dims && cw > 1 ? cw / 2 : (cw + 1) / 2, oh = floor_dims && ch > 1 ? ch / 2 : (ch + 1) / 2;
+            if ((variant & OR_VAR_SIZE_TEST_AFTER) && (ow < 8 || oh < 8)) break;
+            if (variant & OR_VAR_DOWNSAMPLE_XYB) { /* the previous scale's XYB planes averaged, no re-conversion */
+                downsample2_impl(img1, cw, ch, dtmp, floor_dims);
+                memcpy(img1, dtmp, sizeof(float) * 3 * ow * oh);
+                downsample2_impl(img2, cw, ch, dtmp, floor_dims);
+                memcpy(img2, dtmp, sizeof(float) * 3 * ow * oh);
+            } else {
+                downsample2_impl(lin1, cw, ch, dtmp, floor_dims);
+                memcpy(lin1, dtmp, sizeof(float) * 3 * ow * oh);
+                downsample2_impl(lin2, cw, ch, dtmp, floor_dims);
+                memcpy(lin2, dtmp, sizeof(float) * 3 * ow * oh);
+            }
             cw = ow;
             ch = oh;
             /* libjxl tests the size BEFORE downsampling for this scale; the downsampled
                image is scored even if it is now smaller than 8. */
         }
         n = cw * ch;
-        or_linear_to_xyb(lin1, n, img1);
-        or_linear_to_xyb(lin2, n, img2);
+        if (!scale || !(variant & OR_VAR_DOWNSAMPLE_XYB)) {
+            linear_to_xyb_impl(lin1, n, img1, libm_cbrt);
+            linear_to_xyb_impl(lin2, n, img2, libm_cbrt);
+        }
         for (int c = 0; c < 3; ++c) {
             const float *a = img1 + c * n, *b = img2 + c * n;
             float* m = mul + c * n;
+            if (variant & OR_VAR_BLUR_MASK) { /* generic convolution: products rounded first, then blurred */
+                const float* pl[3][2] = {{a, a}, {b, b}, {a, b}};
+                float* outp[3] = {s11 + c * n, s22 + c * n, s12 + c * n};
+                for (int k = 0; k < 3; ++k) {
+                    for (size_t i = 0; i < n; ++i) m[i] = pl[k][0][i] * pl[k][1][i];
+                    conv_plane(&cv, m, cw, ch, tmp, outp[k]);
+                }
+                conv_plane(&cv, a, cw, ch, tmp, mu1 + c * n);
+                conv_plane(&cv, b, cw, ch, tmp, mu2 + c * n);
+                continue;
+            }
             if (blur_mode == OR_BLUR_EXACT) {
                 blur_plane_exact(&rg, a, a, cw, ch, s11 + c * n);
                 blur_plane_exact(&rg, b, b, cw, ch, s22 + c * n);
@@ -671,8 +842,12 @@ int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint3
             blur_plane(&rg, plain_mode, a, cw, ch, tmp, mu1 + c * n);
             blur_plane(&rg, plain_mode, b, cw, ch, tmp, mu2 + c * n);
         }
-        ssim_map(mu1, mu2, s11, s22, s12, n, avg + scale * 18);
-        edge_diff_map(img1, mu1, img2, mu2, n, avg + scale * 18 + 6);
+        if (variant & OR_VAR_SUMS_F32) {
+            maps_f32(img1, mu1, img2, mu2, s11, s22, s12, n, avg + scale * 18);
+        } else {
+            ssim_map(mu1, mu2, s11, s22, s12, n, avg + scale * 18);
+            edge_diff_map(img1, mu1, img2, mu2, n, avg + scale * 18 + 6);
+        }
         ++nscales;
     }
     *out_score = or_score_from_averages(avg, nscales);

@@ -22,6 +22,36 @@ BLUR_EXACT = 2  # the same operator accumulated in fp64 (what both fp32 forms ap
 BLUR_IIR_FMA = 3  # BLUR_IIR with the recursion's multiply-subtract fused: a second fp32 evaluation order
 BLUR_FIR_PRODFIRST = 4  # BLUR_FIR with x*x, y*y, x*y rounded first, then blurred: the published order of operations
 
+# stage variants of the pin kit (OR_VAR_* in ssimu2_oracle.c): single stages switched to plausible alternatives
+VAR_EDGE_CLAMP, VAR_EDGE_MIRROR, VAR_GAUSS9, VAR_GAUSS11 = 0x1, 0x2, 0x4, 0x8
+VAR_DOWNSAMPLE_XYB, VAR_DOWNSAMPLE_FLOOR, VAR_SIZE_TEST_AFTER = 0x10, 0x20, 0x40
+VAR_SRGB_POWF, VAR_CBRT_LIBM, VAR_SUMS_F32 = 0x80, 0x100, 0x200
+
+# The pin kit's catalogue: name -> (blur mode, variant bits, stage, what differs from the published algorithm).
+# The first three are the scorer's blur modes themselves (the only ones the HIP kernels implement); every other
+# entry switches ONE stage, on top of the published recursion and on top of the FIR form.
+PIN_VARIANTS = {
+    "fir": (BLUR_FIR, 0, "blur", "the 9-tap impulse response of the published recursion, products fused into the pair sums (SSIMU2_BLUR_FIR)"),
+    "recursive": (BLUR_IIR, 0, "blur", "the published fp32 recursion, scalar order (SSIMU2_BLUR_RECURSIVE)"),
+    "recursive_fma": (BLUR_IIR_FMA, 0, "blur", "the recursion with its multiply-subtract fused (SSIMU2_BLUR_RECURSIVE_FMA)"),
+    "fir_prodfirst": (BLUR_FIR_PRODFIRST, 0, "blur", "9-tap FIR, products rounded to fp32 first and then blurred"),
+    "fir_edge_clamp": (BLUR_FIR_PRODFIRST, VAR_EDGE_CLAMP, "blur", "9-tap FIR, samples outside the plane replicate the edge"),
+    "fir_edge_mirror": (BLUR_FIR_PRODFIRST, VAR_EDGE_MIRROR, "blur", "9-tap FIR, samples outside the plane mirrored"),
+    "gauss9": (BLUR_FIR_PRODFIRST, VAR_GAUSS9, "blur", "true sigma-1.5 Gaussian, radius 4, normalised, zero padding"),
+    "gauss11": (BLUR_FIR_PRODFIRST, VAR_GAUSS11, "blur", "true sigma-1.5 Gaussian, radius 5, normalised, zero padding"),
+    "gauss9_edge_clamp": (BLUR_FIR_PRODFIRST, VAR_GAUSS9 | VAR_EDGE_CLAMP, "blur", "true Gaussian radius 4, edge replicated"),
+    "gauss11_edge_mirror": (BLUR_FIR_PRODFIRST, VAR_GAUSS11 | VAR_EDGE_MIRROR, "blur", "true Gaussian radius 5, mirrored"),
+}
+for _base, _mode in (("recursive", BLUR_IIR), ("fir", BLUR_FIR)):
+    PIN_VARIANTS.update({
+        f"{_base}+downsample_xyb": (_mode, VAR_DOWNSAMPLE_XYB, "pyramid", "scales 1..5 average the previous scale's XYB planes, not linear light"),
+        f"{_base}+downsample_floor": (_mode, VAR_DOWNSAMPLE_FLOOR, "pyramid", "odd sizes drop the last row / column (floor) instead of replicating it (ceil)"),
+        f"{_base}+size_test_after": (_mode, VAR_SIZE_TEST_AFTER, "pyramid", "a scale is scored only if its own size is >= 8"),
+        f"{_base}+srgb_powf": (_mode, VAR_SRGB_POWF, "colour", "sRGB transfer curve evaluated in fp32 (powf)"),
+        f"{_base}+cbrt_libm": (_mode, VAR_CBRT_LIBM, "colour", "cube root from libm's cbrtf"),
+        f"{_base}+sums_f32": (_mode, VAR_SUMS_F32, "maps", "SSIM / edge maps and their sums in fp32"),
+    })
+
 _libs: dict[bool, ctypes.CDLL] = {}
 
 
@@ -58,6 +88,9 @@ def _lib(omp: bool = False) -> ctypes.CDLL:
                                           ctypes.c_uint32, ctypes.c_int, f64p, f64p,
                                           ctypes.POINTER(ctypes.c_int)]
         lib.or_compute_ssimu2.restype = ctypes.c_int
+        lib.or_compute_ssimu2_variant.argtypes = [u8p, u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                                                  ctypes.c_uint, f64p, f64p, ctypes.POINTER(ctypes.c_int)]
+        lib.or_compute_ssimu2_variant.restype = ctypes.c_int
         lib.or_blur_plane.argtypes = [f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, f32p]
         lib.or_blur_plane.restype = None
         lib.or_blur_product.argtypes = [f32p, f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, f32p]
@@ -118,6 +151,32 @@ def compute_ssimu2(ref: np.ndarray, dist: np.ndarray, blur: int = BLUR_IIR, omp:
     if return_averages:
         return score.value, avg.reshape(6, 18), nsc.value
     return score.value
+
+
+def compute_ssimu2_variant(ref: np.ndarray, dist: np.ndarray, blur: int, variant: int, omp: bool = False,
+                           return_averages: bool = False):
+    """The score with the stages named by the VAR_* bits of `variant` switched to their alternatives (pin kit only;
+    variant = 0 is compute_ssimu2).  Blur variants need blur = BLUR_FIR / BLUR_FIR_PRODFIRST."""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    dist = np.ascontiguousarray(dist, dtype=np.uint8)
+    if ref.shape != dist.shape or ref.ndim != 3 or ref.shape[2] != 3:
+        raise ValueError("ref and dist must both be (h, w, 3) uint8")
+    h, w, _ = ref.shape
+    score = ctypes.c_double(0.0)
+    avg = np.zeros(6 * 18, dtype=np.float64)
+    nsc = ctypes.c_int(0)
+    rc = _lib(omp).or_compute_ssimu2_variant(_u8(ref), _u8(dist), w, h, blur, int(variant), ctypes.byref(score),
+                                             _f64(avg), ctypes.byref(nsc))
+    if rc != 0:
+        raise ValueError(f"or_compute_ssimu2_variant refused blur {blur} / variant {variant:#x} (rc {rc})")
+    if return_averages:
+        return score.value, avg.reshape(6, 18), nsc.value
+    return score.value
+
+
+def pin_variant_score(ref: np.ndarray, dist: np.ndarray, name: str, omp: bool = False) -> float:
+    blur, var, _stage, _what = PIN_VARIANTS[name]
+    return compute_ssimu2_variant(ref, dist, blur, var, omp=omp)
 
 
 def blur_plane(plane: np.ndarray, blur: int = BLUR_IIR) -> np.ndarray:

@@ -64,8 +64,58 @@ def child():
         s.wait()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 200
+        # one stream, whole pair scores back to back, wall clock (what bench.py's `ms_per_score_one_stream` is)
+        for _ in range(20):
+            s.enqueue_device(tr.data_ptr(), td.data_ptr(), w, h)
+        s.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            s.enqueue_device(tr.data_ptr(), td.data_ptr(), w, h)
+        s.wait()
+        torch.cuda.synchronize()
+        dp = (time.perf_counter() - t0) / 200
+        # a blocking score (enqueue + wait each time): the latency one probe of a search sees
+        s.set_reference_device(tr.data_ptr(), w, h)   # the pair scores above dropped the cached reference
+        s.enqueue_against_reference_device(td.data_ptr())
+        s.wait()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            s.enqueue_against_reference_device(td.data_ptr())
+            s.wait()
+        db = (time.perf_counter() - t0) / 100
         print(f"time rep{rep} stage_us[pyramid,march,finalize]={[round(k, 1) for k in ks]} "
-              f"whole_score_us={ms / 50 * 1e3:.1f} cached_pass_us={dt * 1e6:.1f}", flush=True)
+              f"whole_score_us={ms / 50 * 1e3:.1f} cached_pass_us={dt * 1e6:.1f} pair_score_one_stream_us={dp * 1e6:.1f} "
+              f"blocking_cached_pass_us={db * 1e6:.1f}", flush=True)
+    # the search path's default mode: the published recursion, cached reference (same 4K pair)
+    from oavif_amd import _lib
+    if hasattr(s._L, "ssimu2_ctx_set_blur"):
+        s.set_blur(_lib.BLUR_RECURSIVE)
+        rs = s.score_device(tr.data_ptr(), td.data_ptr(), w, h)
+        avg, _ns = s.last_averages()
+        s.set_reference_device(tr.data_ptr(), w, h)
+        s.enqueue_against_reference_device(td.data_ptr())
+        rs2 = s.wait()
+        print("bits", "4k-recursive", struct.pack("<d", rs).hex(), hashlib.sha1(avg.tobytes()).hexdigest()[:16],
+              struct.pack("<d", rs2).hex(), f"{rs:.6f}", flush=True)
+        for rep in range(3):
+            for _ in range(10):
+                s.enqueue_against_reference_device(td.data_ptr())
+            s.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                s.enqueue_against_reference_device(td.data_ptr())
+            s.wait()
+            torch.cuda.synchronize()
+            dr = (time.perf_counter() - t0) / 100
+            t0 = time.perf_counter()
+            for _ in range(50):
+                s.enqueue_against_reference_device(td.data_ptr())
+                s.wait()
+            drb = (time.perf_counter() - t0) / 50
+            print(f"time rep{rep} recursive cached_pass_us={dr * 1e6:.1f} blocking_cached_pass_us={drb * 1e6:.1f}", flush=True)
+        s.set_blur(_lib.BLUR_FIR)
     # 1080p too (config[3]'s frame size)
     w, h = 1920, 1080
     ref = synth.make_ref(w, h, 1)

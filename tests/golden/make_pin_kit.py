@@ -12,7 +12,7 @@ Two kinds of pair:
              written as PNG by `scripts/pin_blur_mode.py --write-pairs DIR`; the kit records their sha256 so a
              regenerated file is known to be the scored one.  Here the modes are 0.4-2 points apart.
 
-Run from the repo root (about two minutes on 8 cores):  python3 tests/golden/make_pin_kit.py
+Run from the repo root (about five minutes on 8 cores):  python3 tests/golden/make_pin_kit.py
 The scores are the checker's, not fssimu2's: parity stays unpinned until somebody runs the kit."""
 import hashlib
 import json
@@ -38,6 +38,13 @@ def three_scores(ref, dst):
             "recursive_fma": orc.compute_ssimu2(ref, dst, orc.BLUR_IIR_FMA, omp=True)}
 
 
+def variant_scores(ref, dst):
+    """Round 5: the score of every entry of the checker's stage-variant catalogue
+    (oracle/ssimu2_oracle.py PIN_VARIANTS: the three blur modes plus single stages switched to plausible
+    alternatives), so that fssimu2's scores of the kit name the STAGE that differs, not only the blur."""
+    return {name: orc.pin_variant_score(ref, dst, name, omp=True) for name in orc.PIN_VARIANTS}
+
+
 def main():
     orc.build()
     orc.set_num_threads(min(16, os.cpu_count() or 1))
@@ -46,9 +53,11 @@ def main():
     # ---- committed pairs -------------------------------------------------------------------------
     ref_a = synth.make_ref(384, 384, 7101)
     ref_b = synth.make_ref(640, 192, 7102)
+    ref_c = synth.make_ref(203, 101, 7103)   # odd at every level (203 -> 102 -> 51 -> 26 -> 13 -> 7) and too small for six scales
     committed = [("a384_avif92", "ref_a384.png", ref_a, synth.avif_roundtrip(ref_a, 92, speed=9)[0], "libavif/aom q92 -> dav1d (Pillow)"),
                  ("a384_avif80", "ref_a384.png", ref_a, synth.avif_roundtrip(ref_a, 80, speed=9)[0], "libavif/aom q80 -> dav1d (Pillow)"),
-                 ("b640_noise1", "ref_b640.png", ref_b, synth.distort(ref_b, "noise", 0, seed=3), "synth.distort(noise, sigma 1)")]
+                 ("b640_noise1", "ref_b640.png", ref_b, synth.distort(ref_b, "noise", 0, seed=3), "synth.distort(noise, sigma 1)"),
+                 ("c203_blockq2", "ref_c203.png", ref_c, synth.distort(ref_c, "blockq", 2, seed=5), "synth.distort(blockq, 2); odd sizes, five scales: the pyramid-stage variants")]
     for name, ref_file, ref, dst, how in committed:
         dist_file = f"dist_{name}.png"
         for fn, px in ((ref_file, ref), (dist_file, dst)):
@@ -57,7 +66,10 @@ def main():
                 open(path, "wb").write(kit.png_rgb8(px))
         pairs.append({"name": name, "kind": "committed", "ref": ref_file, "dist": dist_file, "width": ref.shape[1],
                       "height": ref.shape[0], "distortion": how, "sha256_ref": kit.sha256_pixels(ref),
-                      "sha256_dist": kit.sha256_pixels(dst), "scores": three_scores(ref, dst)})
+                      "sha256_dist": kit.sha256_pixels(dst), "scores": three_scores(ref, dst),
+                      "variant_scores": variant_scores(ref, dst)})
+        if name.startswith("c203"):
+            pairs[-1]["purpose"] = "stages"   # too small for the blur modes to be >= 8 tolerances apart: not a blur-mode pair
         print(name, pairs[-1]["scores"], flush=True)
     # ---- generated pairs (see pin_blur_mode.GENERATED for the recipes) ----------------------------
     for name in kit.GENERATED:
@@ -65,12 +77,18 @@ def main():
         g = kit.GENERATED[name]
         pairs.append({"name": name, "kind": "generated", "ref": f"ref_{name}.png", "dist": f"dist_{name}.png",
                       "width": g["w"], "height": g["h"], "distortion": f"synth.make_ref(seed {g['seed']}) + synth.distort({g['kind']}, {g['strength']})",
-                      "sha256_ref": kit.sha256_pixels(ref), "sha256_dist": kit.sha256_pixels(dst), "scores": three_scores(ref, dst)})
+                      "sha256_ref": kit.sha256_pixels(ref), "sha256_dist": kit.sha256_pixels(dst), "scores": three_scores(ref, dst),
+                      "variant_scores": variant_scores(ref, dst)})
         print(name, pairs[-1]["scores"], flush=True)
     doc = {"what": "blur-mode pin kit: scores of the CPU checker (oracle/ssimu2_oracle.c) in its three blur modes; "
                    "fssimu2 parity UNPINNED until these pairs are scored by fssimu2 0.1.1 (scripts/pin_blur_mode.py)",
            "modes": {"fir": "SSIMU2_BLUR_FIR / OR_BLUR_FIR", "recursive": "SSIMU2_BLUR_RECURSIVE / OR_BLUR_IIR (published scalar order)",
                      "recursive_fma": "SSIMU2_BLUR_RECURSIVE_FMA / OR_BLUR_IIR_FMA (multiply-subtract fused)"},
+           "variants": {name: {"stage": v[2], "what": v[3], "implemented_by_the_hip_scorer": name in ("fir", "recursive", "recursive_fma")}
+                        for name, v in orc.PIN_VARIANTS.items()},
+           "variants_note": "variant_scores[name] per pair: the checker with ONE stage switched to a plausible alternative "
+                            "(oracle/ssimu2_oracle.c OR_VAR_*); scripts/pin_blur_mode.py ranks them against fssimu2's scores and "
+                            "names the stage of the nearest one",
            "tolerance": 0.01, "pairs": pairs}
     json.dump(doc, open(os.path.join(KIT, "pin_kit.json"), "w"), indent=1)
     for p in pairs:

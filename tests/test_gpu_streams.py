@@ -24,7 +24,7 @@ def _ms_per_score(group, pr, pd, w, h, n=240):
 
 def test_contexts_created_back_to_back_get_distinct_queues(hip_lib):
     """What is ASSERTED is collision detection, not a margin: (i) the placed set holds at least two streams
-    (three with HIP's default of four hardware queues: one is the null stream's) -- asked of the instrumented
+    (three or four with HIP's default of four hardware queues: BENCH_r04 reports 4) -- asked of the instrumented
     library instance, which runs the same placement code; (ii) every pair among three product contexts created
     back to back scores faster on two contexts than 0.95 x the one-context time per score (a pair that shares
     a hardware queue measures 1.0; pairs on distinct queues 0.87-0.89, best of four runs each).  The ratio
