@@ -38,6 +38,8 @@ extern fn ssimu2_score_rgb8(ctx: ?*Ctx, ref: [*]const u8, dist: [*]const u8, w: 
 extern fn ssimu2_set_reference(ctx: ?*Ctx, ref: [*]const u8, w: u32, h: u32) c_int;
 extern fn ssimu2_score_against_reference(ctx: ?*Ctx, dist: [*]const u8, out_score: *f64) c_int;
 extern fn ssimu2_score_against_reference_strided(ctx: ?*Ctx, pixels: [*]const u8, row_bytes: u32, channels: u32, out_score: *f64) c_int;
+extern fn ssimu2_host_alloc(ctx: ?*Ctx, bytes: usize, out_ptr: *?*anyopaque) c_int;
+extern fn ssimu2_host_free(ctx: ?*Ctx, ptr: ?*anyopaque) c_int;
 
 /// HIP device the process-wide scorer context binds to (set before the first call; the
 /// batch driver gives every worker process its own device).
@@ -54,20 +56,21 @@ pub var cache_reference: bool = true;
 /// Which blur the scorer evaluates (include/ssimu2_hip.h, ssimu2_ctx_set_blur):
 ///   `.recursive`  DEFAULT of this shim (the search path) since round 4: the published recursive
 ///                 Gaussian operation for operation (libjxl's scalar order; planes bit-identical to the
-///                 CPU checker's), 0.38 ms per 4K pass with the reference cached -- 0.3 % of a pass's
+///                 CPU checker's), 0.37 ms per 4K pass with the reference cached -- 0.1 % of a pass's
 ///                 encode + decode;
 ///   `.recursive_fma`  the same recursion with its multiply-subtract fused (what a compiler targeting
 ///                 an FMA unit makes of the published code);
 ///   `.fir`        the THROUGHPUT mode (what the benchmarks measure, what a context starts in at the
-///                 C ABI): the recursion's exact 9-tap impulse response in fused kernels, 0.16 ms.
+///                 C ABI): the recursion's exact 9-tap impulse response in fused kernels, 0.15 ms.
 /// Why `.recursive`: fssimu2's source was not available where this shim was written, so which fp32
 /// evaluation of the blur it follows is unknown.  The modes differ by the recursion's own rounding
 /// noise -- median 0.02 points on small frames, 0.5 at 4K, where 8 of 24 searches then end on another
 /// quantizer -- and the published SSIMULACRA2 code is the recursion; with the scorer at 0.3 % of a
 /// pass either way, the search follows the published arithmetic.  A maintainer who can run fssimu2
 /// settles it in minutes: tests/golden/pin_kit holds pairs on which the three modes are 0.1 to 3.8
-/// points apart with the score of each, scripts/pin_blur_mode.py takes fssimu2's scores of the same
-/// files and names the mode that matches within +-0.01 (INTEGRATION.md 2e).  Set before the first call.
+/// points apart with the score of each -- and of 19 single-stage variants of the published algorithm --,
+/// scripts/pin_blur_mode.py takes fssimu2's scores of the same files and names the mode that matches
+/// within +-0.01, or the stage that differs (INTEGRATION.md 2e).  Set before the first call.
 pub const Blur = enum(c_int) { fir = 0, recursive = 1, recursive_fma = 2 };
 pub var blur: Blur = .recursive;
 
@@ -167,6 +170,21 @@ pub fn prefetch() void {
 /// (bad arguments, unreadable input), so HIP start-up does not race process teardown.
 pub fn prefetchJoin() void {
     _ = ssimu2_prefetch_join(device);
+}
+
+/// Optional (INTEGRATION.md section 2b): a page-locked buffer for libavif to decode into -- point
+/// `rgb.pixels` at it instead of calling avifRGBImageAllocatePixels (io.zig:475) and the upload of a pass
+/// skips the HIP runtime's staging copy.  Measured a convenience, not a speed-up (the pageable path copies
+/// at PCIe speed already).  Free with freeFrame before deinit().
+pub fn allocFrame(bytes: usize) Error![]u8 {
+    const ctx = try context();
+    var p: ?*anyopaque = null;
+    try check(ssimu2_host_alloc(ctx, bytes, &p));
+    return @as([*]u8, @ptrCast(p.?))[0..bytes];
+}
+
+pub fn freeFrame(frame: []u8) void {
+    if (g_ctx) |c| _ = ssimu2_host_free(c, frame.ptr);
 }
 
 /// Release the GPU context (optional; the process exit does it too).

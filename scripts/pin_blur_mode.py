@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
-"""Which blur does fssimu2 follow?  
+"""Which blur -- and which STAGE -- does fssimu2 follow?  
 
 The scorer has three blur modes -- `fir` (the 9-tap impulse response of the published recursion), `recursive`
 (the published fp32 recursion, scalar order) and `recursive_fma` (its multiply-subtract fused) -- which differ
-by 0.1 to 2 points on the pairs of tests/golden/pin_kit/, far more than the +-0.01 north_star allows.  Which
+by 0.1 to 3.8 points on the pairs of tests/golden/pin_kit/, far more than the +-0.01 north_star allows.  Which
 one fssimu2 0.1.1 agrees with cannot be found out in this repository's build environment (no Zig, no fssimu2
-source).  Someone who can run fssimu2 does it like this:
+source).  And fssimu2 may differ from the published algorithm somewhere else: the kit therefore also records,
+per pair, the CPU checker's score with ONE stage switched to a plausible alternative (blur edge rule, a true
+Gaussian instead of the recursion's impulse response, products rounded first, XYB-domain or floor-sized
+downsampling, the size test after downsampling, fp32 transfer curve, libm cube root, fp32 map sums: 22 entries,
+`--variants` lists them), so that one run of fssimu2 names the stage that differs instead of "no mode matches".
+Someone who can run fssimu2 does it like this:
 
   1. python3 scripts/pin_blur_mode.py --write-pairs DIR       (the kit's pairs as PNG files: the committed
                                                                ones copied, the full-size ones regenerated
                                                                from their seeds and checked against sha256)
   2. score every DIR/ref_*.png against its DIR/dist_*.png with fssimu2 (e.g. `fssimu2 ref.png dist.png`, or
      computeSsimu2 on the decoded RGB8 buffers), and write one line per pair:   name,score
-  3. python3 scripts/pin_blur_mode.py results.txt             prints the mode that matches within +-0.01 on
-                                                               every pair, or how far each mode is
+  3. python3 scripts/pin_blur_mode.py results.txt             prints the distance to every variant, nearest
+                                                               first, and a verdict: MATCH (a blur mode of the
+                                                               scorer within +-0.01 on every pair), STAGE (a
+                                                               variant the scorer does not implement is within
+                                                               +-0.01: that stage differs), or NO VARIANT MATCHES
 
   python3 scripts/pin_blur_mode.py --list                      the pairs and the recorded scores
+  python3 scripts/pin_blur_mode.py --variants                  the catalogue: name, stage, what differs
 
 No dependency beyond numpy + zlib (the PNG reader / writer below handles 8-bit RGB only, which is what the kit
 holds); --write-pairs needs the repo (oavif_amd.synth) for the generated pairs."""
@@ -87,6 +96,22 @@ def load_kit():
     return json.load(open(os.path.join(KIT, "pin_kit.json")))
 
 
+def rank_variants(kit, results):
+    """results: {pair name: score}.  -> [(variant name, worst |d| over the given pairs, mean |d|, stage)], nearest first.
+    Pairs recorded before the catalogue existed (no `variant_scores`) count for the three blur modes only."""
+    by_name = {p["name"]: p for p in kit["pairs"]}
+    out = []
+    for v, meta in kit.get("variants", {m: {"stage": "blur"} for m in MODES}).items():
+        ds = []
+        for name, score in results.items():
+            rec = by_name[name].get("variant_scores") or by_name[name]["scores"]
+            if v in rec:
+                ds.append(abs(score - rec[v]))
+        if ds:
+            out.append((v, max(ds), sum(ds) / len(ds), meta.get("stage", "?")))
+    return sorted(out, key=lambda t: (t[1], t[2]))
+
+
 def classify(kit, results):
     """results: {pair name: score}.  -> (verdict line, per-pair rows, per-mode worst distance)."""
     tol = float(kit.get("tolerance", 0.01))
@@ -101,16 +126,32 @@ def classify(kit, results):
             worst[m] = max(worst[m], d[m])
         rows.append((name, score, d, min(MODES, key=lambda m: d[m])))
     match = [m for m in MODES if worst[m] <= tol]
+    ranked = rank_variants(kit, results) if rows else []
+    close = [r for r in ranked if r[1] <= tol and r[0] not in MODES]     # variants the scorer does not implement
     if not rows:
         verdict = "no results given"
     elif len(match) == 1:
-        verdict = f"MATCH: {match[0]} (every pair within +-{tol}); set the shim's `blur` / OAVIF_SSIMU2_BLUR to it and re-pin the oracle"
+        same = [r[0] for r in close]
+        verdict = (f"MATCH: {match[0]} (every pair within +-{tol}); set the shim's `blur` / OAVIF_SSIMU2_BLUR to it and re-pin the oracle"
+                   + (f" [also within +-{tol}, i.e. not told apart from it by these pairs and not needing to be: {', '.join(same)}]" if same else ""))
     elif match:
         verdict = f"AMBIGUOUS: {', '.join(match)} all within +-{tol} -- score the full-size pairs too (the modes are 0.4-2 points apart there)"
+    elif close:
+        v, w_, _, stage = close[0]
+        what = kit.get("variants", {}).get(v, {}).get("what", "")
+        others = [r[0] for r in close[1:]]
+        verdict = (f"STAGE: no blur mode of the scorer matches, but the checker's variant `{v}` does (every pair within +-{tol}, worst "
+                   f"{w_:.4f}): fssimu2 differs from the published algorithm in the {stage.upper()} stage -- {what}.  The HIP scorer does "
+                   f"not implement that variant; the oracle does (oracle/ssimu2_oracle.c OR_VAR_*): it is the specification of the change"
+                   + (f" [also within +-{tol}: {', '.join(others)}]" if others else ""))
     else:
         near = min(MODES, key=lambda m: worst[m])
-        verdict = (f"NO MODE MATCHES within +-{tol}: nearest is {near} (worst pair {worst[near]:.4f} away); fssimu2 evaluates the "
-                   f"blur in another fp32 order -- its source is then the only way to +-0.01")
+        v, w_, _, stage = ranked[0]
+        verdict = (f"NO MODE MATCHES within +-{tol}: nearest mode is {near} (worst pair {worst[near]:.4f} away); nearest variant of the "
+                   f"catalogue is `{v}` ({stage} stage, worst pair {w_:.4f} away).  "
+                   + ("A distance of a few hundredths to a recursive variant is what a last-bit difference BEFORE the blur looks like "
+                      "(the recursion amplifies it: see the srgb_powf / cbrt_libm rows of --variants); " if w_ <= 0.1 and v.startswith("recursive") else "")
+                   + "fssimu2's source is then the only way to +-0.01")
     return verdict, rows, worst
 
 
@@ -139,6 +180,17 @@ def main(argv):
             open(os.path.join(out, f"dist_{p['name']}.png"), "wb").write(png_rgb8(dst))
             print(f"wrote {p['name']}: ref_{p['name']}.png dist_{p['name']}.png ({p['width']}x{p['height']})")
         return 0
+    if argv[0] == "--variants":
+        for v, meta in kit.get("variants", {}).items():
+            gaps = []
+            for p in kit["pairs"]:
+                vs = p.get("variant_scores", {})
+                base = "recursive" if v.startswith("recursive") else "fir"
+                if v in vs and base in vs:
+                    gaps.append(abs(vs[v] - vs[base]))
+            print(f"{v:28s} {meta['stage']:8s} {'[HIP mode] ' if meta.get('implemented_by_the_hip_scorer') else ''}{meta['what']}"
+                  + (f"   (moves the kit's scores by {min(gaps):.4f} .. {max(gaps):.4f} against `{'recursive' if v.startswith('recursive') else 'fir'}`)" if gaps and max(gaps) > 0 else ""))
+        return 0
     results = {}
     for ln in open(argv[0]):
         ln = ln.strip()
@@ -150,6 +202,9 @@ def main(argv):
     for name, score, d, nearest in rows:
         print(f"{name:16s} given {score:9.4f}   |d| fir {d['fir']:.4f}  recursive {d['recursive']:.4f}  recursive_fma {d['recursive_fma']:.4f}   nearest: {nearest}")
     print("worst distance per mode: " + "  ".join(f"{m} {worst[m]:.4f}" for m in MODES))
+    print("every variant of the catalogue, nearest first (worst / mean |d| over the given pairs):")
+    for v, w_, mean, stage in rank_variants(kit, results):
+        print(f"  {v:28s} {stage:8s} worst {w_:8.4f}  mean {mean:8.4f}")
     print(verdict)
     return 0
 

@@ -64,3 +64,15 @@ int ssimu2_score_against_reference_strided(ssimu2_ctx* c, const uint8_t* pixels,
 int ssimu2_score_against_reference(ssimu2_ctx* c, const uint8_t* dist, double* out_score) { /* referenced by tq.cpp */
     return c ? ssimu2_score_against_reference_strided(c, dist, c->w * 3, 3, out_score) : SSIMU2_ERR_INVALID_ARG;
 }
+/* page-locked frame buffers (round 5): plain heap memory here -- the host's caller-provided-pixels path runs as it
+   does on the GPU box, and ASan checks the buffer's bounds (w * h * 4 bytes) against libavif's writes */
+int ssimu2_host_alloc(ssimu2_ctx* c, size_t bytes, void** out_ptr) {
+    if (!c || !out_ptr || !bytes) return SSIMU2_ERR_INVALID_ARG;
+    *out_ptr = malloc(bytes);
+    return *out_ptr ? SSIMU2_OK : SSIMU2_ERR_OOM;
+}
+int ssimu2_host_free(ssimu2_ctx* c, void* ptr) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    free(ptr);
+    return SSIMU2_OK;
+}

@@ -98,3 +98,48 @@ def test_bench_and_batch_leave_with_rc_4_before_any_rendezvous_when_devices_are_
         src = src[src.index("def main("):]
         assert src.index("collective.preflight(backend, local_world)") < src.index(first) < src.index("collective.check_in(")
         assert src.count("return 4") >= 2
+
+
+# ---- on the MI355X box (one GPU): what RCCL and the launcher really do ----------------------------------------
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_collective_record_through_rccl(hip_lib):
+    """the N = 1 line carries `collective` with world_size 1 gathered through RCCL (a process
+    group of one rank on backend nccl, device tensors), the rank's device as the library sees it, and the versions."""
+    import oavif_amd
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    c = d["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1 and c["problems"] == [], c
+    assert "RCCL process group of one rank" in c["gathered_through"] and "error" not in c
+    info = oavif_amd.query_device(0)
+    r = c["ranks"][0]
+    assert (r["rank"], r["device"], r["pci_bus_id"], r["numa_node"]) == (0, 0, info["pci_bus_id"], info["numa_node"])
+    assert r["arch"].startswith("gfx950") and r["n_cpus"] >= 1
+    assert c["versions"]["rccl"][0].isdigit() and c["versions"]["hip"]
+    m = d["default_search_mode"]
+    assert m["blur"].startswith("recursive") and 0.2 < m["ms_per_pass"] < 0.6 and m["MP_per_s"] < d["value"]
+
+
+@pytest.mark.gpu
+def test_two_rccl_ranks_on_a_one_gpu_box_are_refused_by_bench_and_batch(tmp_path, hip_lib):
+    """Two ranks over RCCL need two devices: on this pool's one-GPU boxes both entry points leave with rc 4 on every
+    rank BEFORE any rendezvous (collective.preflight), so no rank waits for the other and nothing plausible is printed."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    (tmp_path / "imgs").mkdir()
+    from PIL import Image
+    from oavif_amd import synth
+    Image.fromarray(synth.make_ref(64, 48, 1)).save(tmp_path / "imgs" / "a.png")
+    for what in (["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                 ["-m", "oavif_amd.batch", str(tmp_path / "imgs"), str(tmp_path / "o.csv"), "--out-dir", str(tmp_path / "out")]):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), *what], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert p.returncode != 0
+        assert p.stderr.count("refusing to run: 1 visible device(s) for 2 ranks") == 2, p.stderr[-3000:]
+        assert "exitcode  : 4" in p.stderr or "exitcode: 4" in p.stderr, p.stderr[-3000:]
+        assert '"value"' not in p.stdout and not (tmp_path / "o.csv").exists()

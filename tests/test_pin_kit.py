@@ -1,6 +1,7 @@
-"""The blur-mode pin kit (tests/golden/pin_kit/, scripts/pin_blur_mode.py): pairs on which
-the three blur modes differ by 9x to 380x north_star's +-0.01, with the checker's score in each mode, and the
-script that tells from fssimu2's scores of the same files which mode it follows.  Parity vs fssimu2 stays
+"""The pin kit (tests/golden/pin_kit/, scripts/pin_blur_mode.py): pairs on which
+the three blur modes differ by 9x to 380x north_star's +-0.01, with the checker's score in each mode AND in 19
+single-stage variants of the published algorithm (blur edge rule / kernel, pyramid, colour, map sums), and the
+script that tells from fssimu2's scores of the same files which mode it follows -- or which stage differs.  Parity vs fssimu2 stays
 UNPINNED here: the recorded scores are this repo's checker's (self-oracle); the kit is what unpins it.
 
 CPU: the committed files are what the kit says (sha256), the checker reproduces the recorded scores, one
@@ -36,7 +37,8 @@ def test_kit_modes_are_far_apart_and_files_are_the_scored_ones(doc):
     for p in doc["pairs"]:
         s = p["scores"]
         gaps = [abs(s[a] - s[b]) for a, b in (("fir", "recursive"), ("fir", "recursive_fma"), ("recursive", "recursive_fma"))]
-        assert min(gaps) > 8 * doc["tolerance"], p["name"]          # every pair tells the three modes apart
+        if p.get("purpose") != "stages":    # (the small odd-sized pair is there for the pyramid-stage variants)
+            assert min(gaps) > 8 * doc["tolerance"], p["name"]      # every pair tells the three modes apart
         big += min(gaps) >= 0.5
         if p["kind"] == "committed":
             ref, dst = _pixels(p)
@@ -55,6 +57,65 @@ def test_checker_reproduces_the_recorded_scores(doc, oracle):
         for m, flag in modes.items():
             got = oracle.compute_ssimu2(ref, dst, flag, omp=True)
             assert abs(got - p["scores"][m]) < 1e-9, (p["name"], m, got)
+
+
+def test_checker_reproduces_the_recorded_variant_scores(doc, oracle):
+    """Round 5: every entry of the stage-variant catalogue (oracle PIN_VARIANTS) on the small committed pairs; the
+    catalogue in the kit is the checker's, entry for entry; the three blur modes' variant scores ARE the mode scores."""
+    assert set(doc["variants"]) == set(oracle.PIN_VARIANTS) and len(doc["variants"]) == 22
+    assert {v["stage"] for v in doc["variants"].values()} == {"blur", "pyramid", "colour", "maps"}
+    assert [n for n, v in doc["variants"].items() if v["implemented_by_the_hip_scorer"]] == ["fir", "recursive", "recursive_fma"]
+    for p in doc["pairs"]:
+        assert set(p["variant_scores"]) == set(doc["variants"]), p["name"]
+        for m in kit.MODES:
+            assert p["variant_scores"][m] == p["scores"][m]
+    for name in ("c203_blockq2", "b640_noise1"):
+        p = [q for q in doc["pairs"] if q["name"] == name][0]
+        ref, dst = _pixels(p)
+        for v in doc["variants"]:
+            got = oracle.pin_variant_score(ref, dst, v, omp=True)
+            assert abs(got - p["variant_scores"][v]) < 1e-9, (name, v, got)
+    # variant 0 is the oracle proper, bit for bit; contradictory or misplaced bits are refused
+    p = doc["pairs"][3]
+    ref, dst = _pixels(p)
+    assert oracle.compute_ssimu2_variant(ref, dst, oracle.BLUR_FIR, 0) == oracle.compute_ssimu2(ref, dst, oracle.BLUR_FIR)
+    assert oracle.compute_ssimu2_variant(ref, dst, oracle.BLUR_IIR, 0) == oracle.compute_ssimu2(ref, dst, oracle.BLUR_IIR)
+    for blur, var in ((oracle.BLUR_IIR, oracle.VAR_EDGE_CLAMP), (oracle.BLUR_FIR, oracle.VAR_EDGE_CLAMP | oracle.VAR_EDGE_MIRROR),
+                      (oracle.BLUR_FIR, oracle.VAR_GAUSS9 | oracle.VAR_GAUSS11), (oracle.BLUR_FIR, 0x400)):
+        with pytest.raises(ValueError):
+            oracle.compute_ssimu2_variant(ref, dst, blur, var)
+    # each stage variant is visible somewhere in the kit: at least one pair moves by more than the tolerance
+    # (the ones that do not -- products first, fp32 sums, last-bit colour changes under the FIR -- are the ones the
+    # classifier reports as "not told apart and not needing to be")
+    quiet = set()
+    for v in doc["variants"]:
+        base = "recursive" if v.startswith("recursive") else "fir"
+        if v not in kit.MODES and max(abs(q["variant_scores"][v] - q["variant_scores"][base]) for q in doc["pairs"]) <= doc["tolerance"]:
+            quiet.add(v)
+    assert quiet == {"fir_prodfirst", "fir+srgb_powf", "fir+cbrt_libm", "fir+sums_f32", "recursive+sums_f32"}
+
+
+def test_classifier_names_the_stage_for_every_variant(doc):
+    """scores that follow ANY entry of the catalogue are classified -- a blur mode of the scorer
+    (MATCH), a stage the scorer does not implement (STAGE: names the variant and its stage), or, for the five variants
+    that stay within +-0.01 of a mode on every pair, that mode with the variant listed beside it."""
+    quiet = {"fir_prodfirst": "fir", "fir+srgb_powf": "fir", "fir+cbrt_libm": "fir", "fir+sums_f32": "fir", "recursive+sums_f32": "recursive"}
+    for v, meta in doc["variants"].items():
+        res = {p["name"]: p["variant_scores"][v] + 0.003 for p in doc["pairs"]}
+        verdict, _rows, _worst = kit.classify(doc, res)
+        ranked = kit.rank_variants(doc, res)
+        assert ranked[0][1] <= 0.0031 and len(ranked) == 22
+        if v in kit.MODES:
+            assert verdict.startswith(f"MATCH: {v} "), (v, verdict)
+        elif v in quiet:
+            assert verdict.startswith(f"MATCH: {quiet[v]} ") and v in verdict, (v, verdict)
+        else:
+            assert verdict.startswith("STAGE: ") and f"`{v}`" in verdict and f"{meta['stage'].upper()} stage" in verdict, (v, verdict)
+            assert ranked[0][0] == v or ranked[0][1] == ranked[[r[0] for r in ranked].index(v)][1]
+    # a last-bit difference in front of the recursion: no match, and the verdict says what that looks like
+    res = {p["name"]: 0.5 * (p["variant_scores"]["recursive"] + p["variant_scores"]["recursive+srgb_powf"]) + 0.012 for p in doc["pairs"]}
+    verdict, _, _ = kit.classify(doc, res)
+    assert verdict.startswith("NO MODE MATCHES") and "nearest variant of the catalogue is `recursive" in verdict and "last-bit difference" in verdict
 
 
 def test_classifier_verdicts(doc, tmp_path):
@@ -76,9 +137,11 @@ def test_classifier_verdicts(doc, tmp_path):
     import subprocess
     import sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_blur_mode.py"), str(f)], capture_output=True, text=True)
-    assert out.returncode == 0 and "MATCH: recursive (" in out.stdout
+    assert out.returncode == 0 and "MATCH: recursive (" in out.stdout and "every variant of the catalogue, nearest first" in out.stdout
     lst = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_blur_mode.py"), "--list"], capture_output=True, text=True)
     assert "g4k_noise1" in lst.stdout and "a384_avif92" in lst.stdout
+    var = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_blur_mode.py"), "--variants"], capture_output=True, text=True)
+    assert var.returncode == 0 and "fir_edge_mirror" in var.stdout and "recursive+downsample_xyb" in var.stdout and "[HIP mode]" in var.stdout
 
 
 def test_png_round_trip_of_the_kits_writer(tmp_path):
