@@ -62,6 +62,32 @@ def test_workload_is_hbm_fed_and_roofline_is_stated_honestly():
         assert v["frac_measured"] is None or v["frac_nominal"] < v["frac_measured"]
 
 
+def test_line_describes_its_process_group_and_the_search_default_mode():
+    """VERDICT r04 item 1 / ADVICE r04: the line says what the collective saw (backend, world size, per rank the
+    device / PCI bus id / NUMA node / cores, RCCL version) -- at N = 1 through an RCCL group of one rank -- and
+    carries the throughput of the mode the search path runs by default beside `value`."""
+    d = _line()
+    c = d["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == d["n_gpus"] == len(c["ranks"]) and c["problems"] == []
+    assert c["distinct_devices"] == d["n_gpus"] and "RCCL" in c["gathered_through"]
+    for k, r in enumerate(c["ranks"]):
+        assert r["rank"] == k and isinstance(r["device"], int) and r["arch"].startswith("gfx950")
+        assert len(r["pci_bus_id"].split(":")) == 3 and isinstance(r["numa_node"], int) and r["n_cpus"] >= 1 and r["host"]
+    assert set(c["versions"]) >= {"torch", "hip", "rccl"} and c["versions"]["rccl"][0].isdigit()
+    m = d["default_search_mode"]
+    mp = d["config"]["width"] * d["config"]["height"] / 1e6
+    assert m["blur"].startswith("recursive") and abs(m["MP_per_s"] - mp / m["ms_per_pass"] * 1e3) / m["MP_per_s"] < 1e-3
+    assert m["MP_per_s"] < d["value"] and "unpinned" in m["parity"]
+    assert abs(m["ms_per_pass"] - d["recursive_blur_mode"]["cached_reference"]["ms_per_pass"]) < 1e-9
+    k = d["recursive_blur_mode"].get("kernels")
+    if k and "kernels" in k:       # CSV-derived per-kernel times are labelled as not measured by this run; fractions are computed
+        assert "NOT measured by this run" in k["source"]
+        for row in k["kernels"]:
+            assert row["ms_measured_by_this_run"] is False
+            assert abs(row["frac_of_hbm_peak"] - row["algorithmic_bytes"] / row["ms"] / 1e6 / 8000.0) < 2e-3
+        assert abs(k["moved_over_strict_minimum"] - k["bytes_moved_per_pass_GB"] / k["strict_minimum_GB"]) < 0.02
+
+
 def test_counters_file_is_generated_and_stamped():
     """profiles/counters.json comes from scripts/make_counters_json.py and names the kernel
     sources it was measured on; bench.py flags it stale when they differ."""
