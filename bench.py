@@ -319,6 +319,8 @@ def main() -> int:
     # A rank of a multi-rank job pins itself to its slice of the host cores near its GPU before torch / HIP start
     # any thread (oavif_amd.hostinfo, as the batch driver does): the launch thread then sits on the GPU's NUMA node.
     pinned = None
+    if world > 1:   # this pool's driver only supports dmabuf IPC: without it RCCL fails at hipIpcGetMemHandle
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and os.environ.get("OAVIF_BENCH_NO_PIN", "") != "1":
         from oavif_amd import hostinfo as _hi
         pinned = bool(_hi.pin_rank(local_rank, local_world).pinned)

@@ -434,6 +434,8 @@ def main(argv=None) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if world > 1:   # this pool's driver only supports dmabuf IPC: without it RCCL fails at hipIpcGetMemHandle
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Host placement first -- before torch is imported, before any GPU call, before a thread
     # exists: every thread started later (encoder workers, the HIP runtime's) inherits the mask.
     from . import hostinfo

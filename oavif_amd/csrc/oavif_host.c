@@ -302,7 +302,12 @@ static uint8_t* read_file(const char* path, size_t* len) {
         b = g;
         cap *= 2;
     }
-    if (!b || ferror(f)) { fclose(f); free(b); fail(b ? "ReadFailed" : "OutOfMemory", path); return NULL; }
+    if (!b || ferror(f)) {
+        fail(b ? "ReadFailed" : "OutOfMemory", path);
+        fclose(f);
+        free(b);
+        return NULL;
+    }
     fclose(f);
     *len = n;
     return b;

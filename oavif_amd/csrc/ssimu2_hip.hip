@@ -573,7 +573,6 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
     if (p.nscales > 0) {  // a frame below 8 x 8 has no scale to score
         rg_launch_convert(c, p, d_dist, rp);
         const int vgrid = vblocks < c->num_cus ? vblocks : c->num_cus;
-
         rg_launch_h<false>(c, fma, hblocks, rp);
         if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
         else hipLaunchKernelGGL((k_rg_v<false>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
@@ -1010,7 +1009,6 @@ static int ctx_create_impl(int device, void* hip_stream, ssimu2_ctx** out_ctx) {
     CREATE_TRY(hipEventCreate(&c->ev0));
     CREATE_TRY(hipEventCreate(&c->ev1));
     CREATE_TRY(hipMalloc(&c->d_result, 110 * sizeof(double)));
-
     CREATE_TRY(hipHostMalloc(&c->h_result, 110 * sizeof(double), hipHostMallocDefault));
     {
         // The constant table lives in device memory of this module, one copy per device, shared

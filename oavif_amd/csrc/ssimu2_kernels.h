@@ -441,89 +441,6 @@ constexpr int CONV_WAVES = 2;  // each converter lane handles one staged column 
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int RING_ROW = 3 * MRW;  // f2 elements per ring row: [channel][column]
 
-// ---- final reduction ------------------------------------------------------------------------------
-struct FinalizeArgs {
-    const double* part[kNumScales];
-    int nblocks[kNumScales];
-    double inv_pixels[kNumScales];
-    int nscales;
-};
-
-// A launch of its own by measurement (round 5, profiles/r05_finalize_ab.log): folded into the last workgroup of the
-// marching launch (atomic done-counter behind a device-scope release) it made k_march 20 us SLOWER at 4K -- every one
-// of its ~1000 workgroups pays an L2 write-back for the release -- and the recursive pass 2.5 us slower; bits equal.
-// result layout: [0..107] averages [scale][18], [108] score, [109] nscales (host-visible memory: see the end)
-// 8 lanes per (scale, stat) item stride over the workgroup partials; lane-local sums, then a
-// fixed-order 8-lane shuffle tree: deterministic, and NT / 8 items run in parallel instead of 16.
-// Called by all NT threads of a workgroup (NT = 1024: one round of 128 items; 512: two rounds of 64);
-// `s_avg`: 108 doubles, `s_red`: 2 doubles of LDS.
-template <int NT>
-__device__ __forceinline__ void finalize_body(const FinalizeArgs& fa, double* __restrict__ result, double* s_avg,
-                                              double* s_red) {
-    const int tid = threadIdx.x;
-    const int sub = tid & 7;
-#pragma unroll 1
-    for (int item = tid >> 3; item < kNumScales * kStats; item += NT >> 3) {  // the 8 lanes of an item stay together
-        double v = 0.0;
-        const int scale = item / kStats, stat = item - scale * kStats;
-        const bool live = scale < fa.nscales;
-        if (live) {
-            // each lane sums runs of 8 consecutive partials: the 8 loads of a run are independent,
-            // so the loop is 8x shorter than one dependent load + add per partial
-            const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
-            const int nb = fa.nblocks[scale];
-            for (int b = sub * 8; b < nb; b += 64) {
-                double t[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = b + k < nb ? p[b + k] : 0.0;
-                v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-            }
-        }
-        v += __shfl_down(v, 4, 8);
-        v += __shfl_down(v, 2, 8);
-        v += __shfl_down(v, 1, 8);
-        if (sub == 0) {
-            if (live) {
-                v *= fa.inv_pixels[scale];
-                if (stat & 1) v = sqrt(sqrt(v));  // odd stats are L4 norms
-            }
-            s_avg[item] = v;
-        }
-    }
-    __syncthreads();
-    // published Score(): weights are consumed with a running index over (channel, scale present,
-    // norm, {ssim, artifact, detail}); term j of that walk is evaluated by thread j and the
-    // terms are summed with a fixed shuffle tree (two waves), then by thread 0.
-    if (tid < 128) {
-        const int j = tid;
-        const int nterms = 3 * fa.nscales * 2 * 3;
-        double term = 0.0;
-        if (j < nterms) {
-            const int k = j % 3, n = (j / 3) & 1, cs = j / 6;
-            const int sc = cs % fa.nscales, c = cs / fa.nscales;
-            const double* a = s_avg + sc * kStats;
-            const double val = k == 0 ? a[c * 2 + n] : a[6 + c * 4 + n + (k == 2 ? 2 : 0)];
-            term = c_k.weights[j] * fabs(val);
-        }
-        term = wave_sum(term);
-        if ((tid & 63) == 0) s_red[tid >> 6] = term;
-    }
-    __syncthreads();
-    // `result` is the context's page-locked host mirror (the kernel writes the 880 bytes over the bus itself: no
-    // device-side copy of them and no D2H copy command per score): two full-wave stores of consecutive doubles
-    if (tid < kNumScales * kStats) result[tid] = s_avg[tid];
-    if (tid == 0) {
-        double ssim = s_red[0] + s_red[1];
-        ssim = ssim * 0.9562382616834844;
-        ssim = 2.326765642916932 * ssim - 0.020884521182843837 * ssim * ssim +
-               6.248496625763138e-05 * ssim * ssim * ssim;
-        if (ssim > 0.0) ssim = 100.0 - 10.0 * pow(ssim, 0.6276336467831387);
-        else ssim = 100.0;
-        result[108] = ssim;
-        result[109] = (double)fa.nscales;
-    }
-}
-
 struct MarchPlan {
     int nscales;
     int blk_end[kNumScales];   // exclusive end of each scale's block range in the grid
@@ -1062,12 +979,82 @@ __global__ __launch_bounds__(MARCH_THREADS, 6) void k_ref_blur(MarchPlan plan) {
     march_body<MARCH_EMIT>(plan);
 }
 
-// The final reduction as a launch of its own: frames too small for any scale (no marching launch), and the
-// stage timing of the instrumented build.
+// ---- final reduction ------------------------------------------------------------------------------
+struct FinalizeArgs {
+    const double* part[kNumScales];
+    int nblocks[kNumScales];
+    double inv_pixels[kNumScales];
+    int nscales;
+};
+
+// result layout: [0..107] averages [scale][18], [108] score, [109] nscales.  `result` is the context's page-locked
+// host mirror: the kernel writes the 880 bytes over the bus itself (round 5: no device-side copy of them and no D2H
+// copy command per score; -1.7 us per pair score, bits equal).
+// 8 lanes per (scale, stat) item stride over the workgroup partials; lane-local sums, then a
+// fixed-order 8-lane shuffle tree: deterministic, and 128 items run in parallel instead of 16.
+// A launch of its own by measurement (round 5, profiles/r05_finalize_ab.log): folded into the last workgroup of the
+// marching launch (an atomic done-counter behind a device-scope release) it made k_march 20 us SLOWER at 4K -- every
+// one of its ~1000 workgroups pays an L2 write-back for the release -- and the recursive pass 2.5 us slower.
 __global__ __launch_bounds__(1024) void k_finalize(FinalizeArgs fa, double* __restrict__ result) {
     __shared__ double s_avg[kNumScales * kStats];
+    const int item = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    double v = 0.0;
+    const int scale = item / kStats, stat = item - scale * kStats;
+    const bool live = item < kNumScales * kStats && scale < fa.nscales;
+    if (live) {
+        // each lane sums runs of 8 consecutive partials: the 8 loads of a run are independent,
+        // so the loop is 8x shorter than one dependent load + add per partial
+        const double* p = fa.part[scale] + (size_t)stat * fa.nblocks[scale];
+        const int nb = fa.nblocks[scale];
+        for (int b = sub * 8; b < nb; b += 64) {
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = b + k < nb ? p[b + k] : 0.0;
+            v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+    }
+    v += __shfl_down(v, 4, 8);
+    v += __shfl_down(v, 2, 8);
+    v += __shfl_down(v, 1, 8);
+    if (sub == 0 && item < kNumScales * kStats) {
+        if (live) {
+            v *= fa.inv_pixels[scale];
+            if (stat & 1) v = sqrt(sqrt(v));  // odd stats are L4 norms
+        }
+        s_avg[item] = v;
+    }
+    __syncthreads();
+    // published Score(): weights are consumed with a running index over (channel, scale present,
+    // norm, {ssim, artifact, detail}); term j of that walk is evaluated by thread j and the
+    // terms are summed with a fixed shuffle tree (two waves), then by thread 0.
     __shared__ double s_red[2];
-    finalize_body<1024>(fa, result, s_avg, s_red);
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x;
+        const int nterms = 3 * fa.nscales * 2 * 3;
+        double term = 0.0;
+        if (j < nterms) {
+            const int k = j % 3, n = (j / 3) & 1, cs = j / 6;
+            const int sc = cs % fa.nscales, c = cs / fa.nscales;
+            const double* a = s_avg + sc * kStats;
+            const double val = k == 0 ? a[c * 2 + n] : a[6 + c * 4 + n + (k == 2 ? 2 : 0)];
+            term = c_k.weights[j] * fabs(val);
+        }
+        term = wave_sum(term);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = term;
+    }
+    __syncthreads();
+    // the averages leave as two full-wave stores of consecutive doubles (they cross PCIe: not 108 scattered ones)
+    if (threadIdx.x < kNumScales * kStats) result[threadIdx.x] = s_avg[threadIdx.x];
+    if (threadIdx.x == 0) {
+        double ssim = s_red[0] + s_red[1];
+        ssim = ssim * 0.9562382616834844;
+        ssim = 2.326765642916932 * ssim - 0.020884521182843837 * ssim * ssim +
+               6.248496625763138e-05 * ssim * ssim * ssim;
+        if (ssim > 0.0) ssim = 100.0 - 10.0 * pow(ssim, 0.6276336467831387);
+        else ssim = 100.0;
+        result[108] = ssim;
+        result[109] = (double)fa.nscales;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

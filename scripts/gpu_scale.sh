@@ -29,8 +29,19 @@ python3 - <<PY
 import sys; sys.path.insert(0, "$ROOT")
 from PIL import Image
 from oavif_amd import synth
+# content of four kinds, so that the searches do not all end on their first pass (the plain synthetic frame does at
+# target 80): as it is / with sensor-like noise (scores low at the first guess: the search walks up) / smoothed (scores
+# high: walks down) / noise on a smoothed frame -- the passes per image then spread over 1..4 like a folder of photographs
 for i in range($IMAGES):
-    Image.fromarray(synth.make_ref(1920, 1080, 3000 + i)).save("$IMG/img%03d.png" % i, compress_level=1)
+    f = synth.make_ref(1920, 1080, 3000 + i)
+    k = i % 4
+    if k == 1:
+        f = synth.distort(f, "noise", 1 + (i // 4) % 3, seed=i)
+    elif k == 2:
+        f = synth.distort(f, "blur", 1 + (i // 4) % 3)
+    elif k == 3:
+        f = synth.distort(synth.distort(f, "blur", 2), "noise", (i // 4) % 2, seed=i)
+    Image.fromarray(f).save("$IMG/img%03d.png" % i, compress_level=1)
 PY
 PORT=29700
 for N in 1 2 4 8; do
@@ -55,7 +66,7 @@ for N in 1 2 4 8; do
       --collective-json "$OUT/batch_n$N.json" > "$OUT/batch_n$N.log" 2> "$OUT/batch_n$N.err"
   fi
   echo "rc=$?" | tee "$OUT/batch_n$N.rc"
-  grep -E "Images:|Ranks|Total wall|Throughput:|Collective:" "$OUT/batch_n$N.log"
+  grep -E "Images:|Ranks|Total wall|Throughput:|Average passes|Collective:" "$OUT/batch_n$N.log"
   rm -rf "/tmp/oavif_scale_out_$$_$N"
 done
 rm -rf "$IMG"

@@ -24,6 +24,17 @@ def _rc(path):
         return None
 
 
+def _passes(path):
+    """mean / max of the CSV's Passes column (how many scorer passes an image of the batch takes)"""
+    try:
+        rows = list(csv.reader(open(path)))
+        k = rows[0].index("Passes")
+        v = [int(r[k]) for r in rows[1:] if r[k].isdigit()]
+        return {"mean": round(sum(v) / len(v), 2), "max": max(v), "min": min(v)} if v else None
+    except Exception:
+        return None
+
+
 def _rows(path):
     try:
         rows = list(csv.reader(open(path)))
@@ -69,6 +80,7 @@ def main(out_dir):
             e.update({"images": j["images"], "images_ok": j["images_ok"], "wall_s": j["wall_s"], "images_per_s": j["images_per_s"],
                       "speedup_over_1": round(j["images_per_s"] / base_ips, 3) if base_ips and j["images_per_s"] else None,
                       "csv_equals_n1": (rows == base_rows) if rows is not None and base_rows is not None else None,
+                      "passes_per_image": _passes(os.path.join(out_dir, f"batch_n{n}.csv")),
                       "workers_per_rank": j.get("workers_per_rank"), "collective": j["collective"]})
         else:
             e["status"] = "refused" if rc == 4 else "failed"
