@@ -59,7 +59,7 @@ def rank_record(rank: int, local_rank: int, device_index: Optional[int], device_
     return {"rank": int(rank), "local_rank": int(local_rank), "host": socket.gethostname(), "pid": os.getpid(),
             "device": device_index, "pci_bus_id": info.get("pci_bus_id"), "numa_node": info.get("numa_node"),
             "arch": info.get("arch"), "cpus": hostinfo.format_cpus(cpus), "n_cpus": len(cpus),
-            "pinned": pinned}
+            "cpu_numa_nodes": hostinfo.cpu_numa_nodes(cpus), "pinned": pinned}
 
 
 def _encode(rec: dict) -> bytes:
@@ -124,12 +124,24 @@ def problems(records: Sequence[dict], backend: str, world: int, local_world: Opt
     return bad
 
 
+def warnings(records: Sequence[dict]) -> List[str]:
+    """Placements that are legal but not what the design intends (reported on the line, never a refusal): a rank that
+    pinned itself to cores of another NUMA node than the one its GPU hangs off ("host cores near that GPU")."""
+    out: List[str] = []
+    for r in records:
+        nodes, gpu = r.get("cpu_numa_nodes") or [], r.get("numa_node")
+        if r.get("pinned") and gpu is not None and gpu >= 0 and nodes and gpu not in nodes:
+            out.append(f"rank {r.get('rank')} is pinned to cpus {r.get('cpus')} of NUMA node(s) {nodes}, its GPU at "
+                       f"{r.get('pci_bus_id')} hangs off node {gpu}")
+    return out
+
+
 def describe(backend: str, world: int, records: Sequence[dict], through: str, bad: Sequence[str] = ()) -> dict:
     """The `collective` object of the JSON line."""
     distinct = len({(r.get("host"), r.get("pci_bus_id")) for r in records if r.get("pci_bus_id")})
     return {"backend": backend, "world_size": int(world), "gathered_through": through,
             "distinct_devices": distinct, "ranks": list(records), "versions": library_versions(),
-            "problems": list(bad)}
+            "problems": list(bad), "warnings": warnings(records)}
 
 
 def check_in(rank: int, launcher_local_rank: int, device_index: Optional[int], backend: str, world: int,

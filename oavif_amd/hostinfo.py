@@ -64,21 +64,119 @@ def parse_cpulist(text: str) -> List[int]:
 
 def gpu_local_cpulists(sysfs: str = "/sys") -> List[List[int]]:
     """local_cpulist (the cores of the NUMA node a device hangs off) of every AMD display-class PCI
-    function, in PCI address order -- the order the ROCm runtime enumerates devices in when no
-    *_VISIBLE_DEVICES remapping is active.  [] when sysfs does not say."""
-    found = []
-    for dev in sorted(glob.glob(os.path.join(sysfs, "bus/pci/devices/*"))):
+    function, in PCI address order.  [] when sysfs does not say.  (Which of them is HIP device r is NOT this order
+    in general: visible_gpus.)"""
+    return [c for _p, c in amd_gpu_functions(sysfs)]
+
+
+def kfd_gpu_nodes(sysfs: str = "/sys", dev: str = "/dev") -> List[dict]:
+    """The GPU nodes of the KFD topology, in node order -- the order the ROCm runtime enumerates devices in -- each with
+    its PCI address (from `domain` / `location_id`), its DRM render minor and whether THIS process may open that render
+    node (a container that was given one GPU of eight sees all eight in sysfs, but only its own /dev/dri/renderD*: the
+    runtime skips the others the same way).  Nothing here initialises HIP, so a rank can call it before it pins itself.
+    [] when the topology is not there."""
+    out: List[dict] = []
+    nodes = glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*"))
+    try:
+        nodes.sort(key=lambda q: int(os.path.basename(q)))
+    except ValueError:
+        return []
+    for nd in nodes:
+        pr: Dict[str, str] = {}
         try:
-            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+            for ln in open(os.path.join(nd, "properties")):
+                k, _, v = ln.strip().partition(" ")
+                pr[k] = v
+            if int(pr.get("simd_count", "0") or 0) <= 0:
+                continue  # a CPU node
+            loc, dom = int(pr.get("location_id", "0")), int(pr.get("domain", "0"))
+            minor = int(pr.get("drm_render_minor", "-1"))
+        except Exception:
+            continue
+        pci = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        path = os.path.join(dev, f"dri/renderD{minor}")
+        ok = False
+        if minor >= 0 and os.path.exists(path):
+            try:
+                fd = os.open(path, os.O_RDWR)
+                os.close(fd)
+                ok = True
+            except OSError:
+                ok = False
+        out.append({"node": int(os.path.basename(nd)), "pci": pci, "render_minor": minor, "accessible": ok})
+    return out
+
+
+def _visible_filter(n: int) -> Optional[List[int]]:
+    """Indices (into the devices the runtime can open) that ROCR_VISIBLE_DEVICES, then HIP_ / CUDA_VISIBLE_DEVICES
+    leave, in the order they give; None when a variable holds something other than plain indices (UUIDs)."""
+    idx = list(range(n))
+    for group in (("ROCR_VISIBLE_DEVICES",), ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        for var in group:
+            v = os.environ.get(var)
+            if v:
+                try:
+                    pick = [int(t) for t in v.split(",") if t.strip() != ""]
+                except ValueError:
+                    return None
+                idx = [idx[k] for k in pick if 0 <= k < len(idx)]
+                break
+    return idx
+
+
+def visible_gpus(sysfs: str = "/sys", dev: str = "/dev") -> Optional[List[str]]:
+    """PCI addresses of the GPUs this process will see as HIP device 0, 1, ..., found WITHOUT touching the GPU: the GPU
+    nodes of the KFD topology whose render node this process may open, in runtime order, then *_VISIBLE_DEVICES.
+    None when the KFD topology does not say (callers then fall back to sysfs PCI order + *_VISIBLE_DEVICES).
+    Why it matters (round 5, scripts/gpu_topology_probe.py on the pool's boxes): a job that is handed ONE GPU of an
+    eight-GPU host runs with ROCR_VISIBLE_DEVICES=0 -- "the first of the GPUs I can open", which was 0000:f1:00.0,
+    the eighth in PCI order and on NUMA node 1 -- while sysfs lists all eight; reading that 0 as "GPU 0 of the node"
+    pinned the rank to cpus 0-15 on the other socket, and every tenant of the host to the same sixteen."""
+    nodes = kfd_gpu_nodes(sysfs, dev)
+    acc = [n["pci"] for n in nodes if n["accessible"]]
+    if not acc:
+        return None
+    keep = _visible_filter(len(acc))
+    if keep is None:
+        return None
+    return [acc[k] for k in keep]
+
+
+def amd_gpu_functions(sysfs: str = "/sys") -> List[tuple]:
+    """(PCI address, local_cpulist) of every AMD display-class / accelerator PCI function, in PCI address order."""
+    found = []
+    for devdir in sorted(glob.glob(os.path.join(sysfs, "bus/pci/devices/*"))):
+        try:
+            if open(os.path.join(devdir, "vendor")).read().strip() != "0x1002":
                 continue
-            if not open(os.path.join(dev, "class")).read().strip().startswith(("0x03", "0x12")):
-                continue  # display controllers and processing accelerators only
-            cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+            if not open(os.path.join(devdir, "class")).read().strip().startswith(("0x03", "0x12")):
+                continue
+            cpus = parse_cpulist(open(os.path.join(devdir, "local_cpulist")).read())
         except Exception:
             continue
         if cpus:
-            found.append(cpus)
+            found.append((os.path.basename(devdir).lower(), cpus))
     return found
+
+
+def pci_local_cpulist(pci: str, sysfs: str = "/sys") -> List[int]:
+    try:
+        return parse_cpulist(open(os.path.join(sysfs, "bus/pci/devices", pci, "local_cpulist")).read())
+    except Exception:
+        return []
+
+
+def cpu_numa_nodes(cpus: Sequence[int], sysfs: str = "/sys") -> List[int]:
+    """The NUMA nodes the given cpus belong to (sorted; [] when sysfs does not say)."""
+    want = set(cpus)
+    out = []
+    for nd in glob.glob(os.path.join(sysfs, "devices/system/node/node[0-9]*")):
+        try:
+            if want & set(parse_cpulist(open(os.path.join(nd, "cpulist")).read())):
+                out.append(int(os.path.basename(nd)[4:]))
+        except Exception:
+            continue
+    return sorted(out)
 
 
 def sibling_order(cpus: Sequence[int], sysfs: str = "/sys") -> List[int]:
@@ -176,21 +274,43 @@ def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
     return sets
 
 
-def node_core_sets(local_world: int, procs_per_gpu: int = 1) -> List[List[int]]:
-    """rank_core_sets for this node as it is: sysfs topology, cgroup quota, and -- when the job
-    sees only some of the node's GPUs (a shared host: *_VISIBLE_DEVICES) -- only the slices those
-    GPUs would get if every GPU of the node ran a rank, so that tenants of one host pin themselves
-    to different cores.  `procs_per_gpu` consecutive local ranks share a GPU (rank r -> GPU
-    r // procs_per_gpu) and split that GPU's cores."""
-    cpus = sibling_order(allowed_cpus())
-    gpus = gpu_local_cpulists() or None
-    if gpus and procs_per_gpu > 1:
-        gpus = [g for g in gpus for _ in range(procs_per_gpu)]
+def node_core_sets(local_world: int, procs_per_gpu: int = 1, sysfs: str = "/sys", dev: str = "/dev") -> List[List[int]]:
+    """rank_core_sets for this node as it is: sysfs topology, cgroup quota, and the GPUs this job really has.
+    Every GPU of the node owns a slice of the cores of its NUMA node (the slice it would get if every GPU of the node
+    ran one rank); local rank r sits on HIP device r // procs_per_gpu and takes that GPU's slice (ranks that share a
+    GPU split it), cut to the rank's share of the cgroup quota.  So the ranks of a full-node job are near their GPUs,
+    and tenants that were each handed some GPUs of a shared host pin themselves to different cores.
+    Which physical GPU is HIP device r comes from the KFD topology (visible_gpus: runtime order, render nodes this
+    process may open, then *_VISIBLE_DEVICES); without it, sysfs PCI order + *_VISIBLE_DEVICES as before round 5."""
+    cpus = sibling_order(allowed_cpus(), sysfs)
     quota = cgroup_cpu_quota()
+    ppg = max(1, procs_per_gpu)
+    local_world = max(1, int(local_world))
+    allg = amd_gpu_functions(sysfs)
+    mine_pci = visible_gpus(sysfs, dev)
+    if allg and mine_pci:
+        index = {pci: k for k, (pci, _c) in enumerate(allg)}
+        need = -(-local_world // ppg)                      # GPUs this job's ranks sit on
+        if len(mine_pci) >= need and all(p_ in index for p_ in mine_pci[:need]):
+            node = rank_core_sets(len(allg), cpus=cpus, gpu_cpulists=[c for _p, c in allg])
+            sets: List[List[int]] = []
+            for g in range(need):
+                sl = node[index[mine_pci[g]]]
+                k = min(ppg, local_world - g * ppg)
+                sets += rank_core_sets(k, cpus=sl) if k > 1 else [list(sl)]
+            if all(sets):
+                if quota is not None:
+                    share = max(1, int(quota / local_world + 0.5))
+                    core_of = core_groups([c for x in sets for c in x], sysfs)
+                    sets = [one_thread_per_core_first(x, core_of)[:share] if len(x) > share else x for x in sets]
+                return sets
+    gpus = [c for _p, c in allg] or None
+    if gpus and ppg > 1:
+        gpus = [g for g in gpus for _ in range(ppg)]
     vis = visible_gpu_indices()
-    ngpu = len(gpus) // max(1, procs_per_gpu) if gpus else 0
+    ngpu = len(gpus) // ppg if gpus else 0
     if gpus and vis and len(vis) < ngpu and all(0 <= v < ngpu for v in vis):
-        node = rank_core_sets(ngpu, cpus=cpus, gpu_cpulists=gpus[::max(1, procs_per_gpu)])
+        node = rank_core_sets(ngpu, cpus=cpus, gpu_cpulists=gpus[::ppg])
         mine = [c for v in vis for c in node[v]]
         if mine:
             return rank_core_sets(local_world, cpus=mine, quota=quota)
@@ -271,9 +391,17 @@ def busy_fractions(cpus: Sequence[int], sample_s: float = 1.0, sampler=read_cpu_
 
 def gpu_near_pool(procs_per_gpu: int = 1) -> List[int]:
     """The allowed cpus of the NUMA node(s) the visible GPU(s) hang off, hardware threads of a core
-    neighbours; the whole allowed set when sysfs or *_VISIBLE_DEVICES do not say."""
+    neighbours; the whole allowed set when sysfs, the KFD topology and *_VISIBLE_DEVICES do not say."""
     allowed = sibling_order(allowed_cpus())
-    gpus = gpu_local_cpulists()
+    allg = amd_gpu_functions()
+    mine_pci = visible_gpus()
+    if allg and mine_pci:
+        by = dict(allg)
+        nearset = set(c for p_ in mine_pci for c in by.get(p_, []))
+        near = [c for c in allowed if c in nearset]
+        if near:
+            return near
+    gpus = [c for _p, c in allg]
     vis = visible_gpu_indices()
     if gpus and vis and all(0 <= v < len(gpus) for v in vis):
         nearset = set(c for v in vis for c in gpus[v])

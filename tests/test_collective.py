@@ -46,7 +46,7 @@ def test_two_ranks_on_two_devices_are_accepted_and_described(tmp_path, hip_lib):
     for r, bus in zip(c["ranks"], ("0000:05:00.0", "0000:15:00.0")):
         assert r["pci_bus_id"] == bus and r["numa_node"] in (0, 1) and r["arch"].startswith("gfx950")
         assert r["host"] == socket.gethostname() and r["pid"] > 0 and r["n_cpus"] >= 1 and r["cpus"]
-        assert r["local_rank"] == r["rank"] and r["pinned"] in (True, False)
+        assert r["local_rank"] == r["rank"] and r["pinned"] in (True, False) and isinstance(r["cpu_numa_nodes"], list)
     if len(os.sched_getaffinity(0)) >= 2:                            # the ranks pinned themselves to disjoint cores
         from oavif_amd import hostinfo
         a, b = (set(hostinfo.parse_cpulist(r["cpus"])) for r in c["ranks"])
@@ -87,7 +87,14 @@ def test_rules_on_hand_made_records():
     long = dict(rec, cpus=",".join(str(2 * k) for k in range(600)))
     assert len(collective._encode(long)) == collective.RECORD_BYTES and collective._decode(collective._encode(long))["rank"] == 0
     d = collective.describe("nccl", 1, [rec], "x")
-    assert d["world_size"] == 1 and d["distinct_devices"] == 1 and d["ranks"] == [rec]
+    assert d["world_size"] == 1 and d["distinct_devices"] == 1 and d["ranks"] == [rec] and d["warnings"] == []
+    # a rank pinned to the other socket than its GPU's is reported (a warning on the line, not a refusal)
+    far = dict(rec, pinned=True, cpus="0-15", cpu_numa_nodes=[0], numa_node=1, rank=0)
+    near = dict(far, cpus="112-127", cpu_numa_nodes=[1])
+    assert collective.warnings([near]) == [] and collective.problems([far], "nccl", 1, 1, 1) == []
+    w = collective.warnings([far])
+    assert len(w) == 1 and "pinned to cpus 0-15 of NUMA node(s) [0]" in w[0] and "hangs off node 1" in w[0]
+    assert collective.warnings([dict(far, pinned=None)]) == [] and collective.warnings([dict(far, numa_node=-1)]) == []
 
 
 def test_bench_and_batch_leave_with_rc_4_before_any_rendezvous_when_devices_are_missing():

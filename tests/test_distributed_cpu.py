@@ -144,6 +144,91 @@ def test_gpu_numa_topology_is_read_from_sysfs(tmp_path):
     assert sets == [[0, 1], [2, 3], [4, 5]]
 
 
+def _fake_host(tmp_path, kfd_gpus, accessible):
+    """An eight-GPU, two-socket host as this pool's boxes show it in sysfs: 4 GPUs per NUMA node (node 0: cpus 0-63 +
+    SMT siblings 128-191, node 1: 64-127 + 192-255).  `kfd_gpus`: PCI addresses of the KFD topology's GPU nodes in node
+    order; `accessible`: those whose /dev/dri/renderD* this process can open."""
+    pcis = ["0000:0a:00.0", "0000:23:00.0", "0000:5a:00.0", "0000:72:00.0", "0000:8b:00.0", "0000:a4:00.0", "0000:d9:00.0", "0000:f1:00.0"]
+    sysfs, dev = tmp_path / "sys", tmp_path / "dev"
+    for k, addr in enumerate(pcis):
+        d = sysfs / "bus" / "pci" / "devices" / addr
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n")
+        (d / "class").write_text("0x120000\n")
+        (d / "local_cpulist").write_text("0-63,128-191\n" if k < 4 else "64-127,192-255\n")
+        (d / "numa_node").write_text("0\n" if k < 4 else "1\n")
+    for c in range(256):
+        t = sysfs / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        t.mkdir(parents=True)
+        (t / "thread_siblings_list").write_text(f"{c % 128},{c % 128 + 128}\n")
+    for n, cl in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        nd = sysfs / "devices" / "system" / "node" / f"node{n}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for n in (0, 1):                                                   # the two CPU nodes
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\ndrm_render_minor 0\n")
+    (dev / "dri").mkdir(parents=True)
+    for k, addr in enumerate(kfd_gpus):
+        dom, bus, rest = addr.split(":")
+        devn, fn = rest.split(".")
+        loc = (int(bus, 16) << 8) | (int(devn, 16) << 3) | int(fn)
+        nd = nodes / str(2 + k)
+        nd.mkdir(parents=True)
+        (nd / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain {int(dom, 16)}\ndrm_render_minor {128 + 8 * k}\n")
+        if addr in accessible:
+            (dev / "dri" / f"renderD{128 + 8 * k}").write_bytes(b"")
+    return str(sysfs), str(dev)
+
+
+def test_the_rank_pins_near_the_gpu_it_really_has(tmp_path, monkeypatch):
+    """Round 5 (scripts/gpu_topology_probe.py on the pool's boxes): a job handed ONE GPU of an eight-GPU host runs with
+    ROCR_VISIBLE_DEVICES=0 = "the first GPU I can open" -- 0000:f1:00.0 there, the eighth in PCI order, on NUMA node 1.
+    The KFD topology (GPU nodes whose render node this process can open, in runtime order) says which GPU that is; the
+    rank then takes THAT GPU's slice of its NUMA node's cores, so two tenants of one host never share cores -- before,
+    every tenant read the 0 as "GPU 0 of the node" and pinned itself to cpus 0-15 on the other socket."""
+    from oavif_amd import hostinfo
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(256)))
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 16.0)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    sysfs, dev = _fake_host(tmp_path / "a", ["0000:f1:00.0"], {"0000:f1:00.0"})           # the container's view
+    nodes = hostinfo.kfd_gpu_nodes(sysfs, dev)
+    assert [(n["pci"], n["render_minor"], n["accessible"]) for n in nodes] == [("0000:f1:00.0", 128, True)]
+    assert hostinfo.visible_gpus(sysfs, dev) == ["0000:f1:00.0"]
+    mine = hostinfo.node_core_sets(1, sysfs=sysfs, dev=dev)
+    assert mine == [list(range(112, 128))]                          # the fourth GPU of node 1: its quarter, one thread per core
+    assert hostinfo.cpu_numa_nodes(mine[0], sysfs) == [1]
+    sysfs2, dev2 = _fake_host(tmp_path / "b", ["0000:d9:00.0"], {"0000:d9:00.0"})         # the neighbouring tenant
+    other = hostinfo.node_core_sets(1, sysfs=sysfs2, dev=dev2)
+    assert other == [list(range(96, 112))] and not set(other[0]) & set(mine[0])
+    two = hostinfo.node_core_sets(2, procs_per_gpu=2, sysfs=sysfs, dev=dev)               # --procs-per-gpu 2 on that one GPU
+    assert two == [list(range(112, 120)), list(range(120, 128))]
+    # a whole node, the runtime's order not the PCI order, no *_VISIBLE_DEVICES: rank r is near HIP device r
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: None)
+    order = ["0000:8b:00.0", "0000:0a:00.0", "0000:f1:00.0", "0000:23:00.0", "0000:a4:00.0", "0000:5a:00.0", "0000:d9:00.0", "0000:72:00.0"]
+    sysfs3, dev3 = _fake_host(tmp_path / "c", order, set(order))
+    assert hostinfo.visible_gpus(sysfs3, dev3) == order
+    sets = hostinfo.node_core_sets(8, sysfs=sysfs3, dev=dev3)
+    assert len(set(sum(sets, []))) == 256 and all(len(x) == 32 for x in sets)
+    for r, addr in enumerate(order):
+        assert hostinfo.cpu_numa_nodes(sets[r], sysfs3) == [0 if addr in ("0000:0a:00.0", "0000:23:00.0", "0000:5a:00.0", "0000:72:00.0") else 1], (r, addr)
+    # HIP_VISIBLE_DEVICES picks among the GPUs the process can open, in the order it names them
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert hostinfo.visible_gpus(sysfs3, dev3) == ["0000:f1:00.0", "0000:8b:00.0"]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")                               # a UUID: not interpreted
+    assert hostinfo.visible_gpus(sysfs3, dev3) is None
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # no KFD topology (or nothing that can be opened): the sysfs / *_VISIBLE_DEVICES rule of before
+    sysfs4, dev4 = _fake_host(tmp_path / "d", ["0000:f1:00.0"], set())
+    assert hostinfo.visible_gpus(sysfs4, dev4) is None
+    assert hostinfo.node_core_sets(8, sysfs=sysfs4, dev=dev4) == hostinfo.rank_core_sets(
+        8, cpus=hostinfo.sibling_order(range(256), sysfs4), gpu_cpulists=hostinfo.gpu_local_cpulists(sysfs4))
+
+
 def test_idle_cores_are_picked_on_a_shared_host():
     """pick_idle_cpus: two samples of per-cpu ticks; a core is as busy as its busiest hardware
     thread; whole idle cores first; unreadable /proc/stat falls back to one thread per core."""
