@@ -353,10 +353,12 @@ def main() -> int:
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(seconds=300)   # every rank runs the same steps: a collective that waits longer than this is stuck
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
 
     import oavif_amd
     from oavif_amd import synth

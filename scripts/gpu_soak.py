@@ -1,6 +1,7 @@
 """Soak of the scorer's contract on the GPU box: for SECONDS (default 150) six threads, one scorer context each,
-score frames of changing sizes in changing blur modes through all three entry points (pair, cached reference,
-strided RGBA hand-off), re-creating their contexts now and then -- what a batch host does for hours.  Every score
+score frames of changing sizes in changing blur modes through all entry points (pair, cached reference, strided
+RGBA hand-off, and -- round 5 -- the cached-reference pass from a page-locked buffer of ssimu2_host_alloc that is
+allocated, filled and freed every time), re-creating their contexts now and then -- what a batch host does for hours.  Every score
 must equal, bit for bit, the one a single context computed for the same (size, mode, pair) before the threads
 started; device memory must be back where it was when the contexts are gone.
 Usage: gpu_soak.py [SECONDS]"""
@@ -59,7 +60,7 @@ def work(i):
             s.set_blur(_lib.BLUR_FIR if mode is None else mode)
             wh = SIZES[int(rng.integers(0, len(SIZES)))]
             ref, dists = pairs[wh]
-            entry = int(rng.integers(0, 3))
+            entry = int(rng.integers(0, 4))
             if entry:
                 s.set_reference(ref)
             for j, d in enumerate(dists):
@@ -67,6 +68,11 @@ def work(i):
                     got = s.compute_ssimu2(ref, d)
                 elif entry == 1:
                     got = s.score_against_reference(d)
+                elif entry == 3:                       # decode-into-pinned, as csrc/oavif_host.c does
+                    pin = s.host_alloc(d.shape)
+                    pin[...] = d
+                    got = s.score_against_reference(pin)
+                    s.host_free(pin)
                 else:                                  # libavif's RGBA rows with padding behind every row
                     h, w, _ = d.shape
                     rows = np.zeros((h, w * 4 + 24), np.uint8)
@@ -88,7 +94,7 @@ th = [threading.Thread(target=work, args=(i,)) for i in range(NT)]
 [t.start() for t in th]
 [t.join() for t in th]
 after = free_mb()
-print(f"{NT} threads, {time.time() - t0:.0f} s, {sum(counts)} scores over {len(SIZES)} sizes x 3 blur modes x 3 entry points with "
+print(f"{NT} threads, {time.time() - t0:.0f} s, {sum(counts)} scores over {len(SIZES)} sizes x 3 blur modes x 4 entry points with "
       f"contexts re-created now and then: mismatches / errors = {len(errors)}; device memory free before / after: "
       f"{base:.0f} / {after:.0f} MB (difference {base - after:+.0f} MB)")
 for e in errors[:10]:
