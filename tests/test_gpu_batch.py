@@ -119,11 +119,27 @@ print("rccl gather ok")
     for tag, extra in (("plain", {}), ("rccl", {"OAVIF_GATHER_ALWAYS": "1", "MASTER_PORT": str(_free_port())})):
         csv_path = tmp_path / f"{tag}.csv"
         q = subprocess.run([sys.executable, "-m", "oavif_amd.batch", str(img_dir), str(csv_path), "--workers", "2",
-                            "--out-dir", str(tmp_path / tag)], env=dict(env, **extra), cwd=ROOT, capture_output=True,
-                           text=True, timeout=600)
+                            "--out-dir", str(tmp_path / tag), "--collective-json", str(tmp_path / f"{tag}.json")],
+                           env=dict(env, **extra), cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert q.returncode == 0, q.stderr[-2000:]
         outs.append(_rows(csv_path))
     assert outs[0] == outs[1] and len(outs[0][1]) == 4
+    # round 5: what the batch says about its process group and its placement.  The rank pins itself (this pool's cgroup
+    # grants 16 of 256 CPUs) to the slice of the GPU it REALLY has -- found through the KFD topology, not by reading
+    # ROCR_VISIBLE_DEVICES=0 as "GPU 0 of the node" -- so its cores are on its GPU's NUMA node and nothing is warned about
+    import json
+    import oavif_amd
+    info = oavif_amd.query_device(0)
+    plain, rccl = (json.load(open(tmp_path / f"{t}.json")) for t in ("plain", "rccl"))
+    assert plain["collective"]["backend"] == "none" and plain["images_ok"] == 4 and plain["images_per_s"] > 0
+    c = rccl["collective"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and "RCCL, device tensors" in c["gathered_through"]
+    assert c["problems"] == [] and c["warnings"] == [], c
+    r = c["ranks"][0]
+    assert r["pci_bus_id"] == info["pci_bus_id"] and r["numa_node"] == info["numa_node"]
+    if r["pinned"] and info["numa_node"] >= 0:
+        assert r["cpu_numa_nodes"] == [info["numa_node"]], r
+    assert "Collective: backend nccl, world 1, 1 distinct device(s)" in q.stdout
 
 
 def test_exec_mode_with_the_compiled_host_equals_the_in_process_batch(tmp_path):
