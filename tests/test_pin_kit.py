@@ -118,6 +118,32 @@ def test_classifier_names_the_stage_for_every_variant(doc):
     assert verdict.startswith("NO MODE MATCHES") and "nearest variant of the catalogue is `recursive" in verdict and "last-bit difference" in verdict
 
 
+def test_combination_fit_recovers_a_two_stage_and_blur_edge_deviation(doc, oracle):
+    """tests/tools/pin_fit.py: scores that follow NO single entry of the catalogue (here: the FIR with mirrored edges AND
+    XYB-domain downsampling AND the size test after downsampling, 0.003 off) are explained by the greedy search over
+    combinations -- the right base, exactly those three stages, within the tolerance -- where the single-variant
+    classifier can only say how far the nearest entry is."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import pin_fit
+    truth = oracle.VAR_EDGE_MIRROR | oracle.VAR_DOWNSAMPLE_XYB | oracle.VAR_SIZE_TEST_AFTER
+    res = {}
+    for name in ("c203_blockq2", "b640_noise1"):
+        p = [q for q in doc["pairs"] if q["name"] == name][0]
+        ref, dst = _pixels(p)
+        res[name] = oracle.compute_ssimu2_variant(ref, dst, oracle.BLUR_FIR_PRODFIRST, truth) - 0.003
+    verdict, _, _ = kit.classify(doc, res)
+    assert verdict.startswith("NO MODE MATCHES")
+    best, fits = pin_fit.fit(doc, res, log=lambda s: None)
+    assert best["base"] == "fir_prodfirst" and best["within_tolerance"] and best["worst"] < 0.0035
+    assert set(best["stages"]) == {"edge_mirror", "downsample_xyb", "size_test_after"} and best["bits"] == truth
+    assert {f["base"] for f in fits} == {"fir", "fir_prodfirst", "recursive", "recursive_fma"}
+    # scores that ARE a mode need no stage at all
+    res = {n: [q for q in doc["pairs"] if q["name"] == n][0]["scores"]["recursive"] + 0.001 for n in res}
+    best, _ = pin_fit.fit(doc, res, log=lambda s: None)
+    assert best["base"] == "recursive" and best["stages"] == [] and best["within_tolerance"]
+
+
 def test_classifier_verdicts(doc, tmp_path):
     rec = {p["name"]: p["scores"] for p in doc["pairs"]}
     for m in kit.MODES:
