@@ -70,6 +70,30 @@ int main(int argc, char** argv) {
         if (strided != cached) { rc = 98; goto fail; }
     }
 
+    {   /* round 5: the device record the context was created with, and a page-locked frame from the library (what a host
+           points avifRGBImage.pixels at, io.zig:452-482) scoring like the malloc'ed one */
+        ssimu2_device_info di, dq;
+        double pinned_score = 0;
+        void* pin = NULL;
+        memset(&di, 0, sizeof di);
+        di.struct_size = (uint32_t)sizeof di;
+        dq = di;
+        if ((rc = ssimu2_ctx_device_info(ctx, &di)) || (rc = ssimu2_query_device(0, &dq))) goto fail;
+        if (strncmp(di.arch, "gfx950", 6) || di.lds_bytes_per_cu < 160u * 1024u || di.wavefront_size != 64 || !di.usable ||
+            strcmp(di.pci_bus_id, dq.pci_bus_id) || di.compute_units != dq.compute_units) { rc = 97; goto fail; }
+        di.struct_size = 8;   /* a caller compiled against another header */
+        if (ssimu2_ctx_device_info(ctx, &di) != SSIMU2_ERR_INVALID_ARG) { rc = 96; goto fail; }
+        if (ssimu2_host_alloc(ctx, 0, &pin) != SSIMU2_ERR_INVALID_ARG) { rc = 95; goto fail; }
+        if ((rc = ssimu2_host_alloc(ctx, n, &pin))) goto fail;
+        memcpy(pin, dist, n);
+        rc = ssimu2_score_against_reference(ctx, (const uint8_t*)pin, &pinned_score);
+        if (!rc) rc = ssimu2_host_free(ctx, pin);
+        if (rc) goto fail;
+        if (pinned_score != cached || ssimu2_host_free(ctx, NULL) != SSIMU2_OK) { rc = 94; goto fail; }
+        fprintf(stderr, "device %s %s pci %s numa %d cus %u lds %u\n", dq.name, dq.arch, dq.pci_bus_id, dq.numa_node, dq.compute_units,
+                dq.lds_bytes_per_cu);
+    }
+
     oavif_tq_options o;
     oavif_tq_default_options(&o);
     oavif_tq_result res;
