@@ -33,6 +33,8 @@ Extra objects on the JSON line:
                   job's own process group (device tensors through RCCL when the backend is nccl; at N = 1 a
                   process group of one rank is opened for it after the timed region).  The run exits non-zero
                   (rc 4) when two RCCL ranks report one GPU or the host shows fewer devices than ranks.
+  per_rank_own_ms_per_step -- N > 1 only: each rank's own work per step up to its synchronize, before the closing
+                  barrier (median block); `ms_per_step` is the max over ranks of the whole block, so a slow rank shows.
   default_search_mode -- throughput of the mode the SEARCH path runs by default (the published recursion, one
                   cached-reference pass per probe), beside `value` (FIR pair scoring, two contexts).
 """
@@ -450,11 +452,14 @@ def main() -> int:
     # little, so the same block is timed `repeats` times back to back -- as many as make the timed
     # wall >= 0.25 s, the same count on every rank -- and the MEDIAN block is what is reported;
     # min / max are printed beside it.
+    own = []   # this rank's own work per block (up to its synchronize, before the closing barrier): shows a slow rank
+
     def timed_block():
         barrier()
         t_ = time.perf_counter()
         run_steps(args.steps)
         torch.cuda.synchronize()
+        own.append(time.perf_counter() - t_)
         barrier()
         return time.perf_counter() - t_
 
@@ -479,13 +484,16 @@ def main() -> int:
     torch.cuda.synchronize()
     elapsed_resident = time.perf_counter() - t1
 
-    rec = torch.tensor([float(rank), float(score), elapsed], dtype=torch.float64, device=coll_dev)
+    own_median = sorted(own)[len(own) // 2]
+    rec = torch.tensor([float(rank), float(score), own_median], dtype=torch.float64, device=coll_dev)
     if distributed:
         gathered = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(gathered, rec)   # the final RCCL gather of per-rank result records
         scores = [float(g[1]) for g in gathered]
+        per_rank_ms = [round(float(g[2]) / args.steps * 1e3, 5) for g in gathered]   # each rank's OWN work per step (median block)
     else:
         scores = [float(score)]
+        per_rank_ms = None
     t = elapsed
 
     if rank == 0:
@@ -522,6 +530,10 @@ def main() -> int:
         }
         if coll is not None:
             out["collective"] = coll
+        if per_rank_ms is not None:
+            # each rank's own work per step, up to its synchronize and before the closing barrier (median block): `ms_per_step`
+            # is the max over ranks of the whole block, so a rank that is slower than the others shows here
+            out["per_rank_own_ms_per_step"] = per_rank_ms
         out["cache_resident"] = {
             "value": round(args.steps * mp / elapsed_resident, 2),
             "unit": "MP/s per GPU", "ms_per_step": round(elapsed_resident / args.steps * 1e3, 5),
