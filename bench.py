@@ -954,6 +954,10 @@ def main() -> int:
     for sc_ in scorers:
         sc_.close()
     if distributed:
+        # rank 0 has spent some tens of seconds on its extra measurements; the others wait for it here, so that every
+        # rank tears its communicator down while its peers are still alive (a rank that leaves early can make the
+        # others' teardown wait on it)
+        dist.barrier()
         dist.destroy_process_group()
     return 0
 
