@@ -11,6 +11,8 @@
 
 int or_compute_ssimu2(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h, uint32_t channels,
                       int blur_mode, double* out_score, double* avg_out, int* nscales_out);
+int or_compute_ssimu2_variant(const uint8_t* ref, const uint8_t* dist, uint32_t w, uint32_t h, int blur_mode, unsigned variant,
+                              double* out_score, double* avg_out, int* nscales_out);
 void or_copy_rgb_pixels(const uint8_t* src, size_t row_bytes, int src_channels, int w, int h, uint8_t* dst);
 void or_blur_plane(const float* in, uint32_t w, uint32_t h, int mode, float* out);
 void or_downsample2(const float* in, size_t w, size_t h, float* out);
@@ -89,6 +91,45 @@ int main(void) {
         }
         free(ref);
         free(dist);
+    }
+    /* the pin kit's stage variants (round 5): every bit alone and a few combinations on sizes that stress their index
+       arithmetic -- mirrored / clamped edges on planes narrower than the kernel radius, floor-sized odd dimensions
+       down to one pixel, the size test after downsampling on frames that lose a scale, XYB-domain downsampling */
+    {
+        static const int vs[][2] = {{17, 9}, {9, 33}, {8, 8}, {203, 101}, {31, 64}, {1, 40}, {40, 1}, {3, 3}};
+        static const unsigned blur_bits[] = {0x1, 0x2, 0x4, 0x8, 0x5, 0xA, 0x9, 0x6};
+        for (size_t k = 0; k < sizeof vs / sizeof vs[0]; ++k) {
+            const uint32_t w = (uint32_t)vs[k][0], h = (uint32_t)vs[k][1];
+            const size_t n = (size_t)w * h * 3;
+            uint8_t* a = (uint8_t*)malloc(n);
+            uint8_t* b = (uint8_t*)malloc(n);
+            for (size_t i = 0; i < n; ++i) {
+                a[i] = (uint8_t)(rnd() >> 3);
+                b[i] = (uint8_t)(a[i] ^ ((rnd() & 31) == 0 ? 9 : 0));
+            }
+            double score = 0, avg[108];
+            int ns = 0;
+            for (unsigned bit = 0x10; bit <= 0x200; bit <<= 1)
+                for (int mode = 0; mode <= 1; ++mode) /* stage bits on the recursion and on the FIR */
+                    if (or_compute_ssimu2_variant(a, b, w, h, mode, bit, &score, avg, &ns) != 0 || !(score <= 100.0)) {
+                        fprintf(stderr, "stage variant %#x mode %d failed at %ux%u\n", bit, mode, w, h);
+                        return 4;
+                    }
+            for (size_t j = 0; j < sizeof blur_bits / sizeof blur_bits[0]; ++j)
+                if (or_compute_ssimu2_variant(a, b, w, h, 4, blur_bits[j] | (j & 1 ? 0x30u : 0u), &score, avg, &ns) != 0 || !(score <= 100.0)) {
+                    fprintf(stderr, "blur variant %#x failed at %ux%u\n", blur_bits[j], w, h);
+                    return 4;
+                }
+            if (or_compute_ssimu2_variant(a, b, w, h, 1, 0x3FF, &score, avg, &ns) == 0 ||  /* clamp + mirror at once */
+                or_compute_ssimu2_variant(a, b, w, h, 0, 0x1, &score, avg, &ns) == 0 ||    /* a blur bit on the recursion */
+                or_compute_ssimu2_variant(a, b, w, h, 1, 0x400, &score, avg, &ns) == 0) {  /* an unknown bit */
+                fprintf(stderr, "a contradictory variant was accepted at %ux%u\n", w, h);
+                return 4;
+            }
+            checksum += score;
+            free(a);
+            free(b);
+        }
     }
     printf("oracle_sanitize ok: checksum %.6f\n", checksum);
     return 0;
