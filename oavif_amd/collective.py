@@ -56,7 +56,17 @@ def rank_record(rank: int, local_rank: int, device_index: Optional[int], device_
     except Exception:
         cpus = []
     from . import hostinfo
+    # what the placement code ASSUMED this device to be before HIP was up (hostinfo.visible_gpus: KFD topology order):
+    # compared with what the runtime says in warnings()
+    assumed = None
+    try:
+        vg = hostinfo.visible_gpus()
+        if vg and device_index is not None and 0 <= device_index < len(vg):
+            assumed = vg[device_index]
+    except Exception:
+        assumed = None
     return {"rank": int(rank), "local_rank": int(local_rank), "host": socket.gethostname(), "pid": os.getpid(),
+            "assumed_pci_bus_id": assumed,
             "device": device_index, "pci_bus_id": info.get("pci_bus_id"), "numa_node": info.get("numa_node"),
             "arch": info.get("arch"), "cpus": hostinfo.format_cpus(cpus), "n_cpus": len(cpus),
             "cpu_numa_nodes": hostinfo.cpu_numa_nodes(cpus), "pinned": pinned}
@@ -133,6 +143,9 @@ def warnings(records: Sequence[dict]) -> List[str]:
         if r.get("pinned") and gpu is not None and gpu >= 0 and nodes and gpu not in nodes:
             out.append(f"rank {r.get('rank')} is pinned to cpus {r.get('cpus')} of NUMA node(s) {nodes}, its GPU at "
                        f"{r.get('pci_bus_id')} hangs off node {gpu}")
+        if r.get("assumed_pci_bus_id") and r.get("pci_bus_id") and r["assumed_pci_bus_id"] != r["pci_bus_id"]:
+            out.append(f"rank {r.get('rank')}: the placement code took HIP device {r.get('device')} for the GPU at "
+                       f"{r['assumed_pci_bus_id']} (KFD topology order), the runtime says it is {r['pci_bus_id']}")
     return out
 
 

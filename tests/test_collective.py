@@ -95,6 +95,10 @@ def test_rules_on_hand_made_records():
     w = collective.warnings([far])
     assert len(w) == 1 and "pinned to cpus 0-15 of NUMA node(s) [0]" in w[0] and "hangs off node 1" in w[0]
     assert collective.warnings([dict(far, pinned=None)]) == [] and collective.warnings([dict(far, numa_node=-1)]) == []
+    # the KFD-order assumption of the placement code is checked against what the runtime reports
+    assert collective.warnings([dict(near, assumed_pci_bus_id=near["pci_bus_id"])]) == []
+    w = collective.warnings([dict(near, assumed_pci_bus_id="0000:0a:00.0")])
+    assert len(w) == 1 and "took HIP device" in w[0] and "0000:0a:00.0" in w[0]
 
 
 def test_bench_and_batch_leave_with_rc_4_before_any_rendezvous_when_devices_are_missing():

@@ -137,6 +137,7 @@ print("rccl gather ok")
     assert c["problems"] == [] and c["warnings"] == [], c
     r = c["ranks"][0]
     assert r["pci_bus_id"] == info["pci_bus_id"] and r["numa_node"] == info["numa_node"]
+    assert r["assumed_pci_bus_id"] in (None, info["pci_bus_id"])     # the KFD topology named the GPU the runtime then gave us
     if r["pinned"] and info["numa_node"] >= 0:
         assert r["cpu_numa_nodes"] == [info["numa_node"]], r
     assert "Collective: backend nccl, world 1, 1 distinct device(s)" in q.stdout
