@@ -314,15 +314,25 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
 
+    # One command for any N (the reference's batch entry is one command, scripts/measure.py:110-158; the driver's N = 1
+    # shape is `python3 bench.py --gpus 1 ...`): asked for N > 1 ranks with no launcher's world in the environment, this
+    # process starts N fresh copies of itself -- BEFORE torch is imported or a GPU touched -- relays rank 0's JSON line as
+    # its own last stdout line and leaves with the first non-zero child code (oavif_amd/launch.py; a refusal stays rc 4).
+    # Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks run the same code.
+    from oavif_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, label="bench.py")
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if world != args.gpus:   # a launcher announced another world than the command asks for
+        print(f"bench.py: --gpus {args.gpus} but the launcher announced WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     # A rank of a multi-rank job pins itself to its slice of the host cores near its GPU before torch / HIP start
     # any thread (oavif_amd.hostinfo, as the batch driver does): the launch thread then sits on the GPU's NUMA node.
     pinned = None
-    if world > 1:   # this pool's driver only supports dmabuf IPC: without it RCCL fails at hipIpcGetMemHandle
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and os.environ.get("OAVIF_BENCH_NO_PIN", "") != "1":
         from oavif_amd import hostinfo as _hi
         pinned = bool(_hi.pin_rank(local_rank, local_world).pinned)
@@ -330,11 +340,6 @@ def main() -> int:
     import numpy as np
     import torch
     import torch.distributed as dist
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
-            return 2
     distributed = world > 1
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the scorer has no CPU fallback", file=sys.stderr)
@@ -353,33 +358,27 @@ def main() -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import datetime
-        limit = datetime.timedelta(seconds=300)   # every rank runs the same steps: a collective that waits longer than this is stuck
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
-        else:
-            dist.init_process_group(backend=backend, timeout=limit)
 
     import oavif_amd
     from oavif_amd import synth
 
-    # The first thing the process group carries: every rank's description of itself.  A rank / device mix-up ends
-    # the run here (rc 4 on every rank: all of them judge the same gathered records), not in a plausible line.
+    # Before any communicator exists: every rank's description of itself travels through the rendezvous store and is
+    # judged on every rank (collective.open_group).  A rank / device mix-up -- two ranks on one GPU is the case RCCL itself
+    # answers with a hang -- ends the run here with rc 4 on every rank, no RCCL communicator ever created; only then is the
+    # process group opened (eagerly, device_id = this rank's GPU) and the records are confirmed by one all_gather over it.
+    # An RCCL failure at that point is printed with RCCL's own message on every rank and ends the run with rc 5.
     coll = None
     if distributed:
-        coll, bad = collective.check_in(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank, backend, world, local_world,
-                                        tensor_device=coll_dev if backend == "nccl" else None, pinned=pinned)
+        coll, rc_ = collective.open_group(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank, backend, world, local_world,
+                                          pinned=pinned, label="bench.py", timeout_s=300.0)
         if backend != "nccl":
             coll["note"] = "a rehearsal: ranks share devices and the collectives run on CPU tensors; never a reported number"
-        if bad:
+        if rc_:
             if rank == 0:
-                print("bench.py: refusing to run:\n  " + "\n  ".join(bad), file=sys.stderr)
-                print(json.dumps({"metric": "ssimulacra2_megapixels_per_sec", "value": None, "error": "placement refused",
+                print(json.dumps({"metric": "ssimulacra2_megapixels_per_sec", "value": None,
+                                  "error": "placement refused" if rc_ == collective.RC_REFUSED else "process group failed",
                                   "n_gpus": world, "collective": coll}), flush=True)
-            dist.destroy_process_group()
-            return 4
+            return rc_
 
     w, h = args.width, args.height
     mp = w * h / 1e6
@@ -495,6 +494,14 @@ def main() -> int:
         scores = [float(score)]
         per_rank_ms = None
     t = elapsed
+    if distributed:
+        # The job's last collective is behind it: every rank leaves the process group HERE, together (barrier, then
+        # destroy), before rank 0 starts its single-GPU extras (roofline, recursive mode, hand-off) -- no rank sits in an
+        # RCCL kernel for the tens of seconds those take (VERDICT r05 / ADVICE r05), and ranks 1..N-1 are done.
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        dist.destroy_process_group()
 
     if rank == 0:
         value = world * args.steps * mp / t
@@ -953,12 +960,6 @@ def main() -> int:
 
     for sc_ in scorers:
         sc_.close()
-    if distributed:
-        # rank 0 has spent some tens of seconds on its extra measurements; the others wait for it here, so that every
-        # rank tears its communicator down while its peers are still alive (a rank that leaves early can make the
-        # others' teardown wait on it)
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 

@@ -389,6 +389,10 @@ def parse_cli(argv=None):
     ap.add_argument("--max-pass", type=int, default=6)        # parse_args.zig:59
     ap.add_argument("--speed", type=int, default=9)           # parse_args.zig:50
     ap.add_argument("--keep", action="store_true", help="keep the generated .avif files")
+    ap.add_argument("--gpus", type=int, default=None, metavar="N",
+                    help="shard the images over N GPUs of this node, one rank per GPU (times --procs-per-gpu): the command "
+                         "starts its own ranks (oavif_amd/launch.py) unless a launcher such as torch.distributed.run has "
+                         "already announced a world.  Default: 1, or the launcher's WORLD_SIZE")
     ap.add_argument("--workers", type=int, default=default_workers(),
                     help="images encoded concurrently per rank (threads; one scorer context each); "
                          "default: the rank's share of the usable host cores")
@@ -430,12 +434,22 @@ def parse_cli(argv=None):
 
 def main(argv=None) -> int:
     args = parse_cli(argv)
+    # One command, as measure.py is one command (measure.py:110-158): `--gpus N` without a launcher's world in the
+    # environment starts N x --procs-per-gpu fresh ranks of this very command before torch is imported or a GPU touched,
+    # relays rank 0's summary and leaves with the first non-zero rank code (oavif_amd/launch.py).
+    from . import launch
+    ppg_cli = max(1, int(args.procs_per_gpu))
+    if args.gpus is not None and launch.needs_self_launch(args.gpus * ppg_cli):
+        return launch.spawn_ranks([sys.executable, "-m", "oavif_amd.batch"] + list(sys.argv[1:] if argv is None else argv),
+                                  args.gpus * ppg_cli, label="oavif_amd.batch")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
-    if world > 1:   # this pool's driver only supports dmabuf IPC: without it RCCL fails at hipIpcGetMemHandle
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus is not None and args.gpus * ppg_cli != world:
+        print(f"oavif_amd.batch: --gpus {args.gpus} x --procs-per-gpu {ppg_cli} but the launcher announced WORLD_SIZE={world}",
+              file=sys.stderr)
+        return 2
     # Host placement first -- before torch is imported, before any GPU call, before a thread
     # exists: every thread started later (encoder workers, the HIP runtime's) inherits the mask.
     from . import hostinfo
@@ -482,31 +496,28 @@ def main(argv=None) -> int:
     gather_always = os.environ.get("OAVIF_GATHER_ALWAYS", "") == "1"
     if world == 1 and gather_always:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or gather_always:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-
-    # The process group's first job: every rank's description of itself, gathered over the backend the record
-    # gather will use.  Two RCCL ranks on one GPU, or a rank set that is not what the launcher announced, end the
-    # run here on every rank (all judge the same gathered records) instead of in a plausible summary.
+    # Before any communicator exists: every rank's description of itself through the rendezvous store, judged on every
+    # rank (collective.open_group).  Two RCCL ranks on one GPU -- the case RCCL answers with a hang -- or a rank set that
+    # is not what the launcher announced end the run here on every rank (rc 4), no communicator ever created; then the
+    # process group is opened on that store and one all_gather over it confirms the records.  An RCCL failure at that
+    # point ends every rank with rc 5 and RCCL's own message.
     coll_group = world > 1 or gather_always
-    coll, bad = collective.check_in(rank, launcher_local_rank, local_rank, backend, world, local_world,
-                                    tensor_device=torch.device("cuda", local_rank) if coll_group and backend == "nccl" else None,
-                                    pinned=pinned if want_pin else None, grouped=coll_group)
+    if coll_group:
+        coll, rc_ = collective.open_group(rank, launcher_local_rank, local_rank, backend, world, local_world,
+                                          pinned=pinned if want_pin else None, label="oavif_amd.batch")
+    else:
+        coll, bad_ = collective.check_in(rank, launcher_local_rank, local_rank, backend, world, local_world,
+                                         pinned=pinned if want_pin else None, grouped=False)
+        rc_ = collective.RC_REFUSED if bad_ else 0
+        if bad_:
+            print("oavif_amd.batch: refusing to run:\n  " + "\n  ".join(bad_), file=sys.stderr)
     if ppg > 1:
         coll["ranks_per_gpu"] = ppg
-    if bad:
-        if rank == 0:
-            print("oavif_amd.batch: refusing to run:\n  " + "\n  ".join(bad), file=sys.stderr)
-        if coll_group:
-            dist.destroy_process_group()
-        return 4
+    if rc_:
+        return rc_
 
     files = list_images(args.images_dir)
     if not files:

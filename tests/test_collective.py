@@ -1,7 +1,10 @@
-"""The `collective` record and the placement refusal (oavif_amd/collective.py), on CPU: two
-ranks over gloo gather their descriptions exactly as bench.py / the batch driver do over RCCL (the device
-description is injected -- there is no GPU here), and the rules of a real multi-GPU run are applied to them:
-two RCCL ranks on one PCI bus id, or fewer visible devices than local ranks, end the run with rc 4 on EVERY rank.
+"""The `collective` record and the placement refusal (oavif_amd/collective.py), on
+CPU: two ranks exchange their descriptions through the rendezvous store exactly as bench.py / the batch driver do --
+BEFORE any communicator exists (the device description is injected: there is no GPU here) -- and the rules of a real
+multi-GPU run are applied to them: two RCCL ranks on one PCI bus id, or fewer visible devices than local ranks, end
+the run with rc 4 on EVERY rank without the communicator ever being created (a stand-in for RCCL's initialisation that
+fails on that very placement shows the old order would have ended in RCCL's error instead); then the process group is
+opened on the same store and one all_gather over it confirms the records.
 What a line must carry: backend, world size, per rank the host / device index / bus id / NUMA node / pinned cores,
 and the library versions.  The reference has no counterpart: scripts/measure.py:137-158 is a sequential loop."""
 import json
@@ -34,19 +37,35 @@ def _run(world, out, **env):
     return [p.returncode for p in procs], [json.load(open(f"{out}.rank{r}")) for r in range(world)], logs
 
 
+def collective_prefixes():
+    from oavif_amd import collective
+    return collective.ENV_PREFIXES
+
+
+def _init_called(out, world):
+    return [os.path.exists(f"{out}.init_called.rank{r}") for r in range(world)]
+
+
 def test_two_ranks_on_two_devices_are_accepted_and_described(tmp_path, hip_lib):
-    rcs, recs, logs = _run(2, tmp_path / "ok", FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl")
+    rcs, recs, logs = _run(2, tmp_path / "ok", FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl",
+                           HSA_TEST_MARKER="from-the-test", NCCL_DEBUG="WARN", UNRELATED_VARIABLE="not recorded")
     assert rcs == [0, 0], logs
     assert recs[0]["collective"] == recs[1]["collective"] or all(      # every rank holds the same gathered record
         recs[0]["collective"][k] == recs[1]["collective"][k] for k in ("backend", "world_size", "ranks", "problems"))
     c = recs[0]["collective"]
     assert c["backend"] == "nccl" and c["world_size"] == 2 and c["distinct_devices"] == 2 and c["problems"] == []
-    assert "gloo" not in c["gathered_through"] or True
+    # exchanged through the store first, confirmed over the process group afterwards -- and the line says so
+    assert c["gathered_through"].startswith("the rendezvous store (TCP key-value exchange), before any communicator existed")
+    assert "confirmed by one all_gather over the job's process group (RCCL, CPU tensors)" in c["gathered_through"]
+    assert _init_called(tmp_path / "ok", 2) == [True, True]
     assert [r["rank"] for r in c["ranks"]] == [0, 1] and [r["device"] for r in c["ranks"]] == [0, 1]
     for r, bus in zip(c["ranks"], ("0000:05:00.0", "0000:15:00.0")):
         assert r["pci_bus_id"] == bus and r["numa_node"] in (0, 1) and r["arch"].startswith("gfx950")
         assert r["host"] == socket.gethostname() and r["pid"] > 0 and r["n_cpus"] >= 1 and r["cpus"]
         assert r["local_rank"] == r["rank"] and r["pinned"] in (True, False) and isinstance(r["cpu_numa_nodes"], list)
+        # the runtime-steering variables each rank ran under travel with its record
+        assert r["env"]["HSA_TEST_MARKER"] == "from-the-test" and r["env"]["NCCL_DEBUG"] == "WARN"
+        assert all(k.startswith(collective_prefixes()) for k in r["env"])
     if len(os.sched_getaffinity(0)) >= 2:                            # the ranks pinned themselves to disjoint cores
         from oavif_amd import hostinfo
         a, b = (set(hostinfo.parse_cpulist(r["cpus"])) for r in c["ranks"])
@@ -60,6 +79,24 @@ def test_two_rccl_ranks_on_one_bus_id_are_refused_on_every_rank(tmp_path, hip_li
     for r in recs:
         assert len(r["problems"]) == 1 and "ranks 0 and 1 both sit on the GPU at 0000:05:00.0" in r["problems"][0]
         assert r["collective"]["distinct_devices"] == 1 and r["collective"]["problems"] == r["problems"]
+        assert "confirmed" not in r["collective"]["gathered_through"]
+    # the refusal is reached BEFORE the communicator -- the stand-in for RCCL's initialisation (which fails
+    # on exactly this placement) was never called ...
+    assert _init_called(tmp_path / "dup", 2) == [False, False]
+    # ... whereas the old order (communicator first, records over it) ends in RCCL's own error, not in the refusal
+    rcs, recs, _ = _run(2, tmp_path / "legacy", FAKE_BUS="0000:05:00.0,0000:05:00.0", CLAIM_BACKEND="nccl", LEGACY_GROUP_CHECK=1)
+    assert rcs == [1, 1] and all("Duplicate GPU detected" in r["legacy_error"] for r in recs)
+
+
+def test_a_failing_process_group_ends_every_rank_with_rc_5_and_the_backends_message(tmp_path, hip_lib):
+    """an RCCL initialisation failure on a legal placement is not retried and not swallowed: every rank
+    prints the backend's message and leaves with rc 5; the record carries the error."""
+    rcs, recs, logs = _run(2, tmp_path / "fail", FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl", FAIL_INIT=1)
+    assert rcs == [5, 5]
+    for r, log in zip(recs, logs):
+        assert r["rc"] == 5 and "ncclSystemError" in r["collective"]["error"] and r["collective"]["problems"] == []
+        assert "the RCCL process group could not be opened" in log and "ncclSystemError" in log
+    assert _init_called(tmp_path / "fail", 2) == [True, True]
 
 
 def test_fewer_devices_than_ranks_are_refused_with_and_without_a_rendezvous(tmp_path, hip_lib):
@@ -102,13 +139,19 @@ def test_rules_on_hand_made_records():
 
 
 def test_bench_and_batch_leave_with_rc_4_before_any_rendezvous_when_devices_are_missing():
-    """Source-level: both entry points run collective.preflight before init_process_group and check_in right after
-    it, and return 4 on a refusal (they cannot be started here: no GPU)."""
-    for path, first in (("bench.py", "dist.init_process_group"), (os.path.join("oavif_amd", "batch.py"), "dist.init_process_group")):
+    """Source-level: both entry points run collective.preflight, then collective.open_group (store exchange -> judge ->
+    process group), never an init_process_group of their own for the multi-rank job, and hand a refusal's code on (they
+    cannot be started here: no GPU)."""
+    for path in ("bench.py", os.path.join("oavif_amd", "batch.py")):
         src = open(os.path.join(ROOT, path)).read()
         src = src[src.index("def main("):]
-        assert src.index("collective.preflight(backend, local_world)") < src.index(first) < src.index("collective.check_in(")
-        assert src.count("return 4") >= 2
+        assert src.index("collective.preflight(backend, local_world)") < src.index("collective.open_group(")
+        assert "dist.init_process_group" not in src
+        assert "return 4" in src and "return rc_" in src
+        assert src.index("launch.needs_self_launch(") < src.index("import torch")   # the supervisor never touches torch / a GPU
+    src = open(os.path.join(ROOT, "oavif_amd", "collective.py")).read()
+    og = src[src.index("def open_group("):]
+    assert og.index("check_in(") < og.index("return coll, RC_REFUSED") < og.index("dist.init_process_group(")
 
 
 # ---- on the MI355X box (one GPU): what RCCL and the launcher really do ----------------------------------------
@@ -137,11 +180,15 @@ def test_bench_line_carries_the_collective_record_through_rccl(hip_lib):
 @pytest.mark.gpu
 def test_two_rccl_ranks_on_a_one_gpu_box_are_refused_by_bench_and_batch(tmp_path, hip_lib):
     """Two ranks over RCCL need two devices: on this pool's one-GPU boxes both entry points leave with rc 4 on every
-    rank BEFORE any rendezvous (collective.preflight), so no rank waits for the other and nothing plausible is printed."""
+    rank BEFORE any rendezvous (collective.preflight), so no rank waits for the other and nothing plausible is printed --
+    under torch.distributed.run and as the BARE command (`python3 bench.py --gpus 2`: the parent launches the ranks itself
+    and hands their code on, oavif_amd/launch.py)."""
     import torch
     if torch.cuda.device_count() != 1:
         pytest.skip("needs a box with exactly one GPU")
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     (tmp_path / "imgs").mkdir()
     from PIL import Image
     from oavif_amd import synth
@@ -154,3 +201,29 @@ def test_two_rccl_ranks_on_a_one_gpu_box_are_refused_by_bench_and_batch(tmp_path
         assert p.stderr.count("refusing to run: 1 visible device(s) for 2 ranks") == 2, p.stderr[-3000:]
         assert "exitcode  : 4" in p.stderr or "exitcode: 4" in p.stderr, p.stderr[-3000:]
         assert '"value"' not in p.stdout and not (tmp_path / "o.csv").exists()
+    for what in (["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                 ["-m", "oavif_amd.batch", "--gpus", "2", str(tmp_path / "imgs"), str(tmp_path / "o.csv"), "--out-dir", str(tmp_path / "out")]):
+        p = subprocess.run([sys.executable, *what], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert p.returncode == 4, (p.returncode, p.stderr[-3000:])                       # the refusal's code is the command's code
+        assert "launching 2 ranks" in p.stderr and p.stderr.count("refusing to run: 1 visible device(s) for 2 ranks") == 2
+        assert '"value"' not in p.stdout and not (tmp_path / "o.csv").exists()
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_rehearsal_over_gloo_prints_one_line_with_both_ranks(tmp_path, hip_lib):
+    """`OAVIF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 ...` (bare): the parent launches two ranks that share this box's
+    GPU, the records travel through the rendezvous store before the process group exists and are confirmed over it, every
+    rank leaves the group before rank 0's extras, and the parent's last stdout line is rank 0's JSON line (rc 0)."""
+    env = dict(os.environ, OAVIF_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["scores"]) == 2 and len(d["per_rank_own_ms_per_step"]) == 2
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and [r["rank"] for r in c["ranks"]] == [0, 1] and c["problems"] == []
+    assert c["gathered_through"].startswith("the rendezvous store") and "confirmed by one all_gather" in c["gathered_through"]
+    assert all(isinstance(r["env"], dict) for r in c["ranks"])
+    assert d["roofline"]["kernel_ms"] > 0          # rank 0's extras ran after the group was left
