@@ -96,53 +96,189 @@ def load_counters(size):
     return c
 
 
-def recursive_kernel_rooflines(w: int, h: int, n_pad: int, live_pass_ms: float):
-    """Per-kernel achieved HBM rate of the recursive mode's cached pass at 3840x2160: algorithmic bytes (SURVEY 8d:
-    each stage reads its inputs once and writes its outputs once) over the kernel's average duration in the newest
-    profiles/rNN_rg_kernel_stats.csv (rocprofv3 --kernel-trace --stats over scripts/gpu_rg_bench.py)."""
+def rocprof_rg_csv(w: int, h: int):
+    """Average kernel durations (ms) of the recursive pass in the newest committed profiles/rNN_rg_kernel_stats.csv (rocprofv3
+    --kernel-trace --stats over scripts/gpu_rg_bench.py at 3840x2160): the cross-check of the live stage times, never their source."""
     import csv
     import glob
-    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_rg_kernel_stats.csv")))
     if not files or (w, h) != (3840, 2160):
-        return None
-    plane = n_pad * 4   # one fp32 plane over all scales, rows padded
-    want = {"k_pyramid_bands_xyb": ("positive-XYB planes of the decoded frame at every scale, from its bytes",
-                                    w * h * 3 + 3 * plane),
-            "k_rg_h<false, false>": ("horizontal recursion of {y, yy, xy} x 3 channels: reads the XYB planes of both "
-                                     "frames, writes nine planes", 6 * plane + 9 * plane),
-            "k_rg_v<false>": ("vertical recursion + maps: reads the nine planes, the six cached reference planes and "
-                              "the XYB planes of both frames", 21 * plane)}
+        return None, {}
+    keys = {"convert": "k_pyramid_bands_xyb", "h": "k_rg_h<false, false>", "v": "k_rg_v<false>"}
     rows = {}
     with open(files[-1]) as f:
         for r in csv.DictReader(f):
-            for key in want:
-                if key in r["Name"] and (key != "k_rg_v<false>" or "emit" not in r["Name"]):
-                    rows[key] = float(r["AverageNs"]) * 1e-6
-    if len(rows) != len(want):
-        return None
+            for st, key in keys.items():
+                if key in r["Name"] and (st != "v" or "emit" not in r["Name"]):
+                    rows[st] = float(r["AverageNs"]) * 1e-6
+    return os.path.relpath(files[-1], ROOT), rows
+
+
+def recursive_pass_bytes(w: int, h: int):
+    """Algorithmic bytes of the three big launches of a reference-cached recursive pass (each stage reads its inputs
+    once and writes its outputs once), planes as the kernels address them: rows padded to 128 floats (ssimu2_recursive.h)."""
+    n_pad = sum((((w + (1 << k) - 1) >> k) + 127) // 128 * 128 * ((h + (1 << k) - 1) >> k) for k in range(6)
+                if k == 0 or (((w + (1 << (k - 1)) - 1) >> (k - 1)) >= 8 and ((h + (1 << (k - 1)) - 1) >> (k - 1)) >= 8))
+    plane = n_pad * 4   # one fp32 plane over all scales
+    return n_pad, {"convert": w * h * 3 + 3 * plane, "h": 6 * plane + 9 * plane, "v": 21 * plane}
+
+
+def recursive_kernel_rooflines(w: int, h: int, live_pass_ms: float, stage_ms: dict, wall_timed_ms: float, wall_plain_ms: float):
+    """Per-kernel achieved HBM rate of the recursive mode's cached pass: algorithmic bytes over the kernel's average duration
+    MEASURED BY THIS RUN (ssimu2_time_kernels of the instrumented build: every launch of the pass made with a start / stop
+    event pair, i.e. the duration its own dispatch packet recorded, passes rotating over distorted frames); the committed
+    rocprofv3 averages are printed beside them as the cross-check."""
+    n_pad, nbytes = recursive_pass_bytes(w, h)
+    what = {"convert": ("k_pyramid_bands_xyb", "positive-XYB planes of the decoded frame at every scale, from its bytes", "mixed"),
+            "h": ("k_rg_h<false, false>", "horizontal recursion of {y, yy, xy} x 3 channels: reads the XYB planes of both frames, "
+                                          "writes nine planes", "mixed"),
+            "v": ("k_rg_v<false>", "vertical recursion + maps: reads the nine planes, the six cached reference planes and the XYB "
+                                   "planes of both frames", "read")}
     ceil = {"read": 6000.0, "write": 5600.0, "mixed": 5100.0}   # GB/s, profiles/r04_rw_mix.txt (2:3 / 1:1 read:write streams)
-    which = {"k_pyramid_bands_xyb": "mixed", "k_rg_h<false, false>": "mixed", "k_rg_v<false>": "read"}
+    csv_path, csv_ms = rocprof_rg_csv(w, h)
     ks = []
-    for key, (what, nbytes) in want.items():
-        gbps = nbytes / rows[key] / 1e6
-        ks.append({"kernel": key, "what": what, "ms": round(rows[key], 4), "ms_measured_by_this_run": False,
-                   "algorithmic_bytes": int(nbytes), "achieved_GBps": round(gbps, 1),
-                   "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 3),
-                   "frac_of_measured_stream_ceiling": round(gbps / ceil[which[key]], 3), "ceiling": which[key]})
-    moved = sum(k["algorithmic_bytes"] for k in ks)
-    strict = w * h * 3 + 9 * plane    # the distorted frame's bytes + the nine cached reference planes it is compared with
-    return {"source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --kernel-trace --stats of scripts/gpu_rg_bench.py, "
-                      "committed with the round it names; NOT measured by this run -- `live_ms_per_pass` is)",
-            "sum_of_kernels_ms": round(sum(rows.values()), 4), "live_ms_per_pass": round(live_pass_ms, 4),
-            "live_over_sum_of_kernels": round(live_pass_ms / sum(rows.values()), 3), "peak_GBps": HBM_PEAK_GBS,
-            "measured_stream_ceilings_GBps": dict(ceil, source="profiles/r04_rw_mix.txt"),
-            "kernels": ks,
-            "bytes_moved_per_pass_GB": round(moved / 1e9, 3), "strict_minimum_GB": round(strict / 1e9, 3),
-            "moved_over_strict_minimum": round(moved / strict, 2),
-            "note": "per-kernel fractions are computed from the byte counts and the CSV's durations; the h -> v round "
-                    "trip of nine planes is the largest part of what is moved beyond the strict minimum (DESIGN.md "
-                    "section 4: why it stays)"}
+    for st, (kernel, text, which) in what.items():
+        gbps = nbytes[st] / stage_ms[st] / 1e6
+        k = {"kernel": kernel, "what": text, "ms": round(stage_ms[st], 4), "ms_measured_by_this_run": True,
+             "algorithmic_bytes": int(nbytes[st]), "achieved_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 3),
+             "frac_of_measured_stream_ceiling": round(gbps / ceil[which], 3), "ceiling": which}
+        if st in csv_ms:
+            k["ms_rocprofv3_committed"] = round(csv_ms[st], 4)
+        ks.append(k)
+    ks.append({"kernel": "k_finalize", "what": "fixed-order fp64 sums, 108 averages, polynomial (latency, no stream)",
+               "ms": round(stage_ms["finalize"], 4), "ms_measured_by_this_run": True})
+    total = sum(stage_ms.values())
+    moved = sum(nbytes.values())
+    strict = w * h * 3 + 9 * n_pad * 4    # the distorted frame's bytes + the nine cached reference planes it is compared with
+    out = {"source": "this run: ssimu2_time_kernels (instrumented build of the same sources: the library's own enqueue path, every "
+                     "launch with a start / stop event pair = the duration its dispatch packet recorded), 48 passes rotating over the "
+                     "distorted frames (HBM-fed)",
+           "sum_of_kernels_ms": round(total, 4),
+           "stream_ms_per_pass_with_timestamps": round(wall_timed_ms, 4), "stream_ms_per_pass_plain_launches": round(wall_plain_ms, 4),
+           "between_launches_ms": round(wall_plain_ms - total, 4),
+           "live_ms_per_pass": round(live_pass_ms, 4),
+           "live_ms_per_pass_note": "the PRODUCT library's pass, host clock over a run of passes (cached_reference.ms_per_pass)",
+           "live_over_sum_of_kernels": round(live_pass_ms / total, 3), "peak_GBps": HBM_PEAK_GBS,
+           "measured_stream_ceilings_GBps": dict(ceil, source="profiles/r04_rw_mix.txt"),
+           "kernels": ks,
+           "bytes_moved_per_pass_GB": round(moved / 1e9, 3), "strict_minimum_GB": round(strict / 1e9, 3),
+           "moved_over_strict_minimum": round(moved / strict, 2),
+           "note": "the h -> v round trip of nine planes is the largest part of what is moved beyond the strict minimum (DESIGN.md "
+                   "section 4: why it stays)"}
+    if csv_path:
+        out["rocprofv3_cross_check"] = {"source": csv_path + " (rocprofv3 --kernel-trace --stats of scripts/gpu_rg_bench.py, committed "
+                                                             "with the round it names; another box)",
+                                        "sum_of_kernels_ms": round(sum(csv_ms.values()), 4)}
+    return out
+
+
+def by_resolution(local_rank: int, t_ref, t_dst, fir_ctxs, budget_s: float = 1.0):
+    """north_star: "throughput on synthetic RGB frames at the named resolutions"; SURVEY 8(d) names 512x512, 1920x1080,
+    3840x2160 and 7680x4320.  Per size, on fresh contexts, every input resident in HBM and rotating over enough distinct pairs
+    to exceed the 256 MiB Infinity Cache: FIR pair scoring on two contexts (what `value` is at 4K; `fir_ctxs` = the timed
+    region's own two contexts, whose streams sit on distinct hardware queues) with its W-model fraction, the same on one
+    stream, the recursive mode's reference-cached pass (the search path's default) on one stream, and every kernel's own
+    duration in both modes (instrumented build, dispatch-packet timestamps) beside the stream time of a score: the difference
+    is what the launches of a score wait between them.  Frames are cut from / tiled out of the 4K synthetic pair on the
+    device (crops at stepped offsets; 8K = the 4K frame and its mirror images, 2 x 2)."""
+    import torch
+    import oavif_amd
+    from oavif_amd import _lib
+    W0, H0 = t_ref.shape[1], t_ref.shape[0]
+    out = []
+
+    def frames_of(w, h, k):
+        if (w, h) == (W0, H0):
+            a, b = torch.roll(t_ref, (k * 977) % W0, 1), torch.roll(t_dst, (k * 977) % W0, 1)
+        elif w <= W0 and h <= H0:
+            nx, ny = max(1, (W0 - w) // 256 + 1), max(1, (H0 - h) // 256 + 1)
+            x0, y0 = min((k % nx) * 256, W0 - w), min(((k // nx) % ny) * 256, H0 - h)
+            a, b = t_ref[y0:y0 + h, x0:x0 + w], t_dst[y0:y0 + h, x0:x0 + w]
+            if (k // (nx * ny)) & 1:
+                a, b = a.flip(1), b.flip(1)
+        else:   # 2 x 2 of the frame and its mirror images (no seams: every neighbour is a reflection)
+            def tile(t):
+                t = torch.roll(t, (k * 977) % W0, 1)
+                top = torch.cat([t, t.flip(1)], 1)
+                return torch.cat([top, top.flip(0)], 0)[:h, :w]
+            a, b = tile(t_ref), tile(t_dst)
+        return a.contiguous(), b.contiguous()
+
+    for (w, h) in ((512, 512), (1920, 1080), (3840, 2160), (7680, 4320)):
+        mp = w * h / 1e6
+        npairs = max(4, -(-272_000_000 // (2 * w * h * 3)))
+        npairs += npairs & 1                      # even: the two contexts walk disjoint halves
+        pairs = [frames_of(w, h, k) for k in range(npairs)]
+        ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in pairs]
+        torch.cuda.synchronize()
+        rec = {"width": w, "height": h, "megapixels": round(mp, 4), "distinct_pairs": npairs,
+               "input_working_set_MB": round(npairs * 2 * w * h * 3 / 1e6, 1)}
+        c0, c1 = fir_ctxs[0], fir_ctxs[1 % len(fir_ctxs)]
+
+        def run(ctxs, n):
+            for i in range(n):
+                c = ctxs[i % len(ctxs)]
+                pr, pd = ptrs[i % npairs]
+                c.enqueue_device(pr, pd, w, h)
+            sc = None
+            for c in ctxs[:min(n, len(ctxs))]:
+                sc = c.wait()
+            return sc
+
+        def rate(ctxs):
+            run(ctxs, max(2 * npairs, 64))                       # capacity, clocks
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(ctxs, 32)
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - t0) / 32, 1e-6)
+            n = int(min(20000, max(32, budget_s / 4 / per)))
+            t0 = time.perf_counter()
+            run(ctxs, n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        ms2 = rate([c0, c1]) if c1 is not c0 else None
+        ms1 = rate([c0])
+        if ms2 is not None:
+            rec["fir_pair_two_contexts"] = {"ms_per_score": round(ms2, 5), "MP_per_s": round(mp / ms2 * 1e3, 1),
+                                            "w_model_frac": round(ALGO_BYTES_PER_PX_SCORE * w * h / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        rec["fir_pair_one_stream"] = {"ms_per_score": round(ms1, 5), "MP_per_s": round(mp / ms1 * 1e3, 1),
+                                      "w_model_frac": round(ALGO_BYTES_PER_PX_SCORE * w * h / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        with oavif_amd.Ssimu2(local_rank, blur=_lib.BLUR_RECURSIVE) as rc_:
+            rc_.set_reference_device(ptrs[0][0], w, h)
+            dists = [p[1] for p in ptrs]
+
+            def run_r(n):
+                for i in range(n):
+                    rc_.enqueue_against_reference_device(dists[i % npairs])
+                return rc_.wait()
+            run_r(max(npairs, 32))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_r(16)
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - t0) / 16, 1e-6)
+            n = int(min(10000, max(16, budget_s / 4 / per)))
+            t0 = time.perf_counter()
+            run_r(n)
+            torch.cuda.synchronize()
+            msr = (time.perf_counter() - t0) / n * 1e3
+            rec["recursive_cached_pass_one_stream"] = {"ms_per_pass": round(msr, 5), "MP_per_s": round(mp / msr * 1e3, 1)}
+        # where the time goes (VERDICT r05 item 5): every kernel of a score / of a pass by its own dispatch-packet timestamps
+        # (instrumented build) against the stream time per score of the same run with plain launches
+        kp = min(npairs, 64)
+        with oavif_amd.Ssimu2(local_rank, instrumented=True) as ic:
+            st, _wt, wp = ic.time_kernels(w, h, [p[1] for p in ptrs[:kp]], 96, d_refs=[p[0] for p in ptrs[:kp]])
+            rec["fir_kernels_ms"] = dict({k: round(v, 5) for k, v in st.items()}, sum=round(sum(st.values()), 5),
+                                         stream_ms_per_score=round(wp, 5), between_launches_ms=round(wp - sum(st.values()), 5))
+        with oavif_amd.Ssimu2(local_rank, instrumented=True, blur=_lib.BLUR_RECURSIVE) as irc:
+            st, _wt, wp = irc.time_kernels(w, h, [p[1] for p in ptrs[:kp]], 96, d_ref=ptrs[0][0], recursive=True)
+            rec["recursive_kernels_ms"] = dict({k: round(v, 5) for k, v in st.items()}, sum=round(sum(st.values()), 5),
+                                               stream_ms_per_pass=round(wp, 5), between_launches_ms=round(wp - sum(st.values()), 5))
+        out.append(rec)
+        del pairs
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline_child(argv) -> int:
@@ -751,16 +887,30 @@ def main() -> int:
                         f"{out['value']} MP/s; the same cached-reference pass in FIR mode: {out['cached_reference']['MP_per_s']} MP/s",
             "parity": "both modes are checked against this repository's CPU oracle only; fssimu2 parity unpinned"}
 
-        # per-kernel rooflines of the recursive pass: the three launches of a reference-cached pass with their
-        # algorithmic bytes (planes as the kernels address them: rows padded to 128 floats) against the rocprofv3
-        # kernel-trace averages committed with the round (the same source the PMC traffic of `roofline` comes
-        # from: profiles/); the live whole-pass time above is the cross-check (it is their sum)
+        # per-kernel rooflines of the recursive pass: its four launches timed LIVE where they run (instrumented build, HIP events
+        # on the pass's own stream around each launch, passes rotating over the distorted frames) with their algorithmic bytes
+        # (planes as the kernels address them: rows padded to 128 floats); the product library's whole-pass time above is the
+        # cross-check (their sum), the committed rocprofv3 averages a second one
         try:
-            rk = recursive_kernel_rooflines(w, h, n_pad, rc_ms)
-            if rk:
-                out["recursive_blur_mode"]["kernels"] = rk
+            with oavif_amd.Ssimu2(local_rank, instrumented=True, blur=_abi.BLUR_RECURSIVE) as irsc:
+                st_ms, st_wt, st_wp = irsc.time_kernels(w, h, dists, 48, d_ref=p_ref, recursive=True)
+            out["recursive_blur_mode"]["kernels"] = recursive_kernel_rooflines(w, h, rc_ms, st_ms, st_wt, st_wp)
         except Exception as e:  # the record is optional
             out["recursive_blur_mode"]["kernels"] = {"error": str(e)[:200]}
+
+        # ---- the named resolutions (north_star): 512^2, 1080p, 4K, 8K -- N = 1 only ----
+        if world == 1 and (w, h) == (W, H):
+            try:
+                t_br = time.perf_counter()
+                out["by_resolution"] = {"sizes": by_resolution(local_rank, t_ref, t_dst, scorers),
+                                        "seconds": None,
+                                        "note": "MP = scale-0 pixels of one image; every input resident in HBM, rotating over "
+                                                "`distinct_pairs` pairs (> 256 MiB of frames); w_model_frac = 85.97 B/px x pixels / "
+                                                "time / 8 TB/s (SURVEY 8d W-model, a model fraction); parity of every size: this "
+                                                "repository's CPU oracle only (fssimu2 parity unpinned)"}
+                out["by_resolution"]["seconds"] = round(time.perf_counter() - t_br, 2)
+            except Exception as e:
+                out["by_resolution"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
         # ---- one search pass as the boundary sees it: host `dist` in, score out ---------------
         scorer.set_reference(ref)

@@ -74,6 +74,27 @@ int ssimu2_instr_cache_reference_blur(ssimu2_ctx* ctx, int enabled);
    algorithmic bytes of one launch (every plane element read once, written once). */
 int ssimu2_time_blur_stage_rotating(ssimu2_ctx* ctx, const void* const* d_frames, int nframes, uint32_t w,
                                     uint32_t h, int iters, float* out_ms_avg, double* out_bytes_per_launch);
+/* Every kernel of a score, timed where it runs.  `iters` (<= 512) scores are enqueued through the library's own enqueue path
+   with each launch made through hipExtLaunchKernelGGL and a start / stop event pair: the kernel's duration as its dispatch
+   packet recorded it (what rocprofv3's kernel trace reads), no packet added between the launches of a score.
+     d_refs == NULL: reference-cached passes against `d_ref` (ssimu2_set_reference_device is called here), rotating over the
+                     n (<= 256) device-resident distorted frames d_dists[] so that every pass is HBM-fed.  Launches per pass --
+                     FIR: k_pyramid_bands, k_march_refblur, k_finalize; recursive: k_pyramid_bands_xyb, k_rg_h, k_rg_v, k_finalize.
+     d_refs != NULL: pair scores of (d_refs[i], d_dists[i]).  FIR: k_pyramid_bands, k_march, k_finalize; recursive: the
+                     reference's three launches, then the pass's four.
+   out_ms_avg[k] (room for 8) = average milliseconds of the k-th launch of a score; *out_launches = launches per score;
+   *out_ms_wall_timed / *out_ms_wall_plain = stream time per score (one event pair around all the scores) with and without
+   the per-launch timestamps -- wall_plain minus the sum of the kernels is what the launches of a score wait between them. */
+int ssimu2_time_kernels(ssimu2_ctx* ctx, const void* d_ref, const void* const* d_refs, const void* const* d_dists, int n,
+                        uint32_t w, uint32_t h, int iters, float* out_ms_avg, int* out_launches, float* out_ms_wall_timed,
+                        float* out_ms_wall_plain);
+/* The hipGraph experiment: with `enabled` = 1 every score of this context is submitted as ONE launch of
+   an instantiated graph -- a chain of kernel nodes, one per launch of the score, kept per context and rewritten per score with
+   hipGraphExecKernelNodeSetParams as long as the chain keeps its shape (same kernels, grids, blocks), rebuilt otherwise --
+   instead of one hipLaunchKernelGGL per kernel.  Same kernels, same arguments, same order: the bits of a score do not change.
+   `enabled` < 0 only reads the counters: graphs built / graph launches so far.  The measured outcome is in
+   profiles/r06_graph_ab.log; the product library does not have this path. */
+int ssimu2_instr_use_graph(ssimu2_ctx* ctx, int enabled, unsigned long long* out_builds, unsigned long long* out_launches);
 /* Stream placement (ssimu2_hip.hip "stream placement"): how many streams on distinct hardware queues this
    library instance holds for ctx's device -- contexts created without a caller stream borrow them in turn.
    3 with HIP's default of four hardware queues; 1 would mean every probe misread (tests/test_gpu_streams.py). */

@@ -108,7 +108,7 @@ INSTR_SYMBOLS = ("ssimu2_debug_download", "ssimu2_time_device", "ssimu2_time_sta
                  "ssimu2_time_march_rotating", "ssimu2_measure_read_stream",
                  "ssimu2_instr_set_segment_rows", "ssimu2_instr_cache_reference_blur",
                  "ssimu2_instr_rg_stop_after_scale", "ssimu2_time_blur_stage_rotating",
-                 "ssimu2_instr_placed_streams")
+                 "ssimu2_instr_placed_streams", "ssimu2_time_kernels", "ssimu2_instr_use_graph")
 
 TQ_MAX_FANOUT = 16
 BATCH_PROBE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
@@ -211,8 +211,11 @@ def _load(path: str, instrumented: bool) -> ctypes.CDLL:
             "ssimu2_instr_cache_reference_blur": [vp, ci],
             "ssimu2_instr_rg_stop_after_scale": [vp, ci],
             "ssimu2_instr_placed_streams": [vp, ctypes.POINTER(ci)],
+            "ssimu2_instr_use_graph": [vp, ci, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)],
             "ssimu2_time_blur_stage_rotating": [vp, ctypes.POINTER(vp), ci, u32, u32, ci,
                                                 ctypes.POINTER(ctypes.c_float), f64p],
+            "ssimu2_time_kernels": [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, u32, u32, ci, ctypes.POINTER(ctypes.c_float),
+                                    ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
         }
         for name, argtypes in sigs.items():
             if hasattr(L, name):  # scripts/gpu_ab.py also binds older builds that lack some hooks

@@ -20,6 +20,9 @@
 // pass, vertical pass + maps, k_finalize); everything on the ctx stream, no host sync inside (enqueue / wait
 // split).  Streams the library creates are placed on distinct hardware queues ("stream placement").
 #include <hip/hip_runtime.h>
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+#include <hip/hip_ext.h>
+#endif
 
 #include <ctype.h>
 #include <math.h>
@@ -182,6 +185,16 @@ struct ssimu2_ctx {
     int seg_rows_tail_override = 0;
     bool cache_ref_blur = true;
     int rg_dbg_scale = -1;  // recursive mode: keep that scale's 15 raw planes (after each pass) downloadable
+    // the hipGraph experiment of the instrumented build (ssimu2_instr_use_graph): one instantiated chain of kernel nodes
+    bool use_graph = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_n = 0;
+    hipGraphNode_t graph_node[8];
+    void* graph_func[8];
+    dim3 graph_grid[8], graph_block[8];
+    unsigned graph_lds[8];
+    unsigned long long graph_builds = 0, graph_launches = 0;
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];
@@ -199,6 +212,80 @@ namespace {
         hipError_t e_ = (call);                                              \
         if (e_ != hipSuccess) return (ctx)->fail(SSIMU2_ERR_HIP, #call, e_); \
     } while (0)
+
+// Every kernel of a score goes through launch().  Product build: hipLaunchKernelGGL, nothing else.  Instrumented build
+// (ssimu2_instrument.hip): while a timing scope is open on the calling thread the same launch is made with
+// hipExtLaunchKernelGGL and a start / stop event pair, so the duration of each kernel comes from its own dispatch packet
+// (what rocprofv3's kernel trace reads) with no marker or barrier packet added between the launches of a score.
+template <class T>
+struct arg_of { using type = T; };
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+struct LaunchTimer {
+    hipEvent_t* ev;  // cap events: launch k of the scope uses ev[2k] (start) and ev[2k + 1] (stop)
+    int n, cap;
+};
+thread_local LaunchTimer* g_launch_timer = nullptr;
+
+// The hipGraph experiment (ssimu2_instr_use_graph): while a recorder is open the launches of one score
+// are not made but noted -- function, geometry, a copy of the arguments -- and enqueue_score() hands the chain to
+// graph_flush(), which keeps one instantiated graph of kernel nodes per context, rewrites the nodes' parameters with
+// hipGraphExecKernelNodeSetParams when the chain has the shape of the last one (same functions, grids, blocks) and
+// launches the graph: one submission per score instead of one per kernel.
+struct LaunchRecorder {
+    static constexpr int kMax = 8, kArgBytes = 1024, kMaxArgs = 12;
+    int n = 0;
+    void* func[kMax];
+    dim3 grid[kMax], block[kMax];
+    unsigned lds[kMax];
+    alignas(16) unsigned char blob[kMax][kArgBytes];
+    void* argv[kMax][kMaxArgs];
+    int nargs[kMax];
+    bool overflow = false;
+};
+thread_local LaunchRecorder* g_launch_recorder = nullptr;
+
+template <typename T>
+inline void record_arg(LaunchRecorder* r, int k, size_t* off, const T& v) {
+    const size_t a = alignof(T) > 16 ? 16 : alignof(T);
+    *off = (*off + a - 1) / a * a;
+    if (*off + sizeof(T) > LaunchRecorder::kArgBytes || r->nargs[k] >= LaunchRecorder::kMaxArgs) {
+        r->overflow = true;
+        return;
+    }
+    memcpy(r->blob[k] + *off, &v, sizeof(T));
+    r->argv[k][r->nargs[k]++] = r->blob[k] + *off;
+    *off += sizeof(T);
+}
+#endif
+template <typename... KArgs>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream,
+                   typename arg_of<KArgs>::type... args) {
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+    if (LaunchRecorder* r = g_launch_recorder) {
+        if (r->n < LaunchRecorder::kMax) {
+            const int k = r->n++;
+            r->func[k] = (void*)kernel;
+            r->grid[k] = grid;
+            r->block[k] = block;
+            r->lds[k] = lds;
+            r->nargs[k] = 0;
+            size_t off = 0;
+            (record_arg<KArgs>(r, k, &off, args), ...);
+        } else {
+            r->overflow = true;
+        }
+        return;
+    }
+    if (LaunchTimer* t = g_launch_timer) {
+        if (t->n + 2 <= t->cap) {
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, t->ev[t->n], t->ev[t->n + 1], 0, args...);
+            t->n += 2;
+            return;
+        }
+    }
+#endif
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
 
 struct Pyramid {
     int w[kNumScales], h[kNumScales];
@@ -347,7 +434,7 @@ void launch_pyramid(ssimu2_ctx* c, const Pyramid& p, int nframes, const uint8_t*
                     float* const* lin) {
     if (p.nscales < 2) return;
     const PyrBandArgs a = pyramid_args(p, nframes, frames, lin);
-    hipLaunchKernelGGL(k_pyramid_bands, dim3(a.bands_x * a.bands_y * nframes), dim3(PYR_THREADS), 0, c->stream, a);
+    launch(k_pyramid_bands, dim3(a.bands_x * a.bands_y * nframes), dim3(PYR_THREADS), 0, c->stream, a);
 }
 
 // float offset of scale s in the cached reference XYB buffer (scale 0 first)
@@ -522,7 +609,7 @@ void rg_launch_convert(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_frame, 
     a.zero4 = rp.q;
     for (int l = 0; l < a.nlevels; ++l) a.out[0][l] = rp.xout[l + 1];
     for (int l = 0; l < p.nscales && l < 6; ++l) a.opitch[l] = rp.pitch[l];
-    hipLaunchKernelGGL(k_pyramid_bands_xyb, dim3(a.bands_x * a.bands_y), dim3(PYR_THREADS), 0, c->stream, a);
+    launch(k_pyramid_bands_xyb, dim3(a.bands_x * a.bands_y), dim3(PYR_THREADS), 0, c->stream, a);
 }
 
 // The horizontal pass: one workgroup per 20 rows and channel (RG_H_PERSISTENT = 1, an A/B build: one
@@ -531,11 +618,11 @@ template <bool REF>
 void rg_launch_h(ssimu2_ctx* c, bool fma, int hblocks, const RgPlan& rp) {
     if (hblocks <= 0) return;
 #if RG_H_PERSISTENT
-    if (fma) hipLaunchKernelGGL((k_rg_h_persistent<true, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
-    else hipLaunchKernelGGL((k_rg_h_persistent<false, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
+    if (fma) launch((k_rg_h_persistent<true, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
+    else launch((k_rg_h_persistent<false, REF>), dim3(c->num_cus), dim3(64 * RG_HW), 0, c->stream, rp);
 #else
-    if (fma) hipLaunchKernelGGL((k_rg_h<true, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
-    else hipLaunchKernelGGL((k_rg_h<false, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
+    if (fma) launch((k_rg_h<true, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
+    else launch((k_rg_h<false, REF>), dim3(hblocks), dim3(REF ? 128 : 192), 0, c->stream, rp);
 #endif
 }
 
@@ -551,8 +638,8 @@ void rg_enqueue_reference(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_ref)
     rg_launch_convert(c, p, d_ref, rp);
     rg_launch_h<true>(c, fma, hblocks, rp);
     if (dbg) rg_debug_keep_h(c, p, rp, true);
-    if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
-    else hipLaunchKernelGGL((k_rg_v_emit<false, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
+    if (fma) launch((k_rg_v_emit<true, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
+    else launch((k_rg_v_emit<false, 2>), dim3(vblocks), dim3(128), 0, c->stream, rp);
 }
 
 // One pass against the reference planes in place: XYB of the distorted frame, the recursion over
@@ -574,17 +661,17 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
         rg_launch_convert(c, p, d_dist, rp);
         const int vgrid = vblocks < c->num_cus ? vblocks : c->num_cus;
         rg_launch_h<false>(c, fma, hblocks, rp);
-        if (fma) hipLaunchKernelGGL((k_rg_v<true>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
-        else hipLaunchKernelGGL((k_rg_v<false>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
+        if (fma) launch((k_rg_v<true>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
+        else launch((k_rg_v<false>), dim3(vgrid), dim3(512), c->rg_v_pad, c->stream, rp);
         if (dbg) {
             rg_debug_keep_h(c, p, rp, false);
             const int s = c->rg_dbg_scale;
             rp.emit[s] = c->d_rg_dbg + (size_t)15 * rg_pitch(p.w[s]) * p.h[s];  // [channel][{y, yy, xy}][n]
-            if (fma) hipLaunchKernelGGL((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
-            else hipLaunchKernelGGL((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
+            if (fma) launch((k_rg_v_emit<true, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
+            else launch((k_rg_v_emit<false, 3>), dim3(vblocks), dim3(192), 0, c->stream, rp);
         }
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);  // result: see enqueue_score
+    launch(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);  // result: see enqueue_score
     HIP_TRY(c, hipGetLastError());
     c->pending = true;
     return SSIMU2_OK;
@@ -592,8 +679,8 @@ int rg_enqueue_pass(ssimu2_ctx* c, const Pyramid& p, const uint8_t* d_dist) {
 
 // Enqueue the whole score of (d_ref, d_dist) on the ctx stream.  `ref_pyramid_ready`:
 // the reference's linear pyramid in d_lin_ref is already valid for this frame size.
-int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, uint32_t w,
-                  uint32_t h, bool ref_pyramid_ready) {
+int enqueue_score_launches(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, uint32_t w,
+                           uint32_t h, bool ref_pyramid_ready) {
     const Pyramid p = make_pyramid(w, h);
     const bool recursive = c->blur_mode != SSIMU2_BLUR_FIR;
     if (recursive) {  // before anything is enqueued
@@ -625,15 +712,84 @@ int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, ui
     build_plans(c, p, d_ref, d_dist, ref_pyramid_ready && c->d_xyb_ref != nullptr, &mp, &fa, &blocks);
     if (blocks > 0) {
         if (mp.ref_s11[0])  // reference XYB and blur(ref*ref) cached: the search's per-pass kernel
-            hipLaunchKernelGGL(k_march_refblur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+            launch(k_march_refblur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
         else
-            hipLaunchKernelGGL(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+            launch(k_march, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
     }
     // the 880-byte result goes straight into the context's page-locked mirror: no D2H copy command per score
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);
+    launch(k_finalize, dim3(1), dim3(1024), 0, c->stream, fa, c->h_result);
     HIP_TRY(c, hipGetLastError());
     c->pending = true;
     return SSIMU2_OK;
+}
+
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+void graph_drop(ssimu2_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->graph_n = 0;
+}
+
+// The recorded chain of one score as ONE graph launch (see LaunchRecorder).
+int graph_flush(ssimu2_ctx* c, LaunchRecorder& r) {
+    if (r.overflow) return c->fail(SSIMU2_ERR_INVALID_ARG, "hipGraph experiment: a score's launches do not fit the recorder");
+    if (r.n == 0) return SSIMU2_OK;
+    bool same = c->graph_exec != nullptr && c->graph_n == r.n;
+    for (int k = 0; same && k < r.n; ++k)
+        same = c->graph_func[k] == r.func[k] && c->graph_lds[k] == r.lds[k] && c->graph_grid[k].x == r.grid[k].x &&
+               c->graph_grid[k].y == r.grid[k].y && c->graph_grid[k].z == r.grid[k].z && c->graph_block[k].x == r.block[k].x &&
+               c->graph_block[k].y == r.block[k].y && c->graph_block[k].z == r.block[k].z;
+    hipKernelNodeParams kp[LaunchRecorder::kMax];
+    for (int k = 0; k < r.n; ++k) {
+        memset(&kp[k], 0, sizeof kp[k]);
+        kp[k].func = r.func[k];
+        kp[k].gridDim = r.grid[k];
+        kp[k].blockDim = r.block[k];
+        kp[k].sharedMemBytes = r.lds[k];
+        kp[k].kernelParams = r.argv[k];
+        kp[k].extra = nullptr;
+    }
+    if (!same) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the old executable graph may still be running
+        graph_drop(c);
+        HIP_TRY(c, hipGraphCreate(&c->graph, 0));
+        for (int k = 0; k < r.n; ++k) {
+            HIP_TRY(c, hipGraphAddKernelNode(&c->graph_node[k], c->graph, k ? &c->graph_node[k - 1] : nullptr, k ? 1 : 0, &kp[k]));
+            c->graph_func[k] = r.func[k];
+            c->graph_grid[k] = r.grid[k];
+            c->graph_block[k] = r.block[k];
+            c->graph_lds[k] = r.lds[k];
+        }
+        HIP_TRY(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        c->graph_n = r.n;
+        ++c->graph_builds;
+    } else {
+        for (int k = 0; k < r.n; ++k) HIP_TRY(c, hipGraphExecKernelNodeSetParams(c->graph_exec, c->graph_node[k], &kp[k]));
+    }
+    HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    ++c->graph_launches;
+    return SSIMU2_OK;
+}
+#endif
+
+// Enqueue the whole score of (d_ref, d_dist) on the ctx stream (enqueue_score_launches above makes the launches; the
+// instrumented build's hipGraph experiment submits them as one graph instead).
+int enqueue_score(ssimu2_ctx* c, const uint8_t* d_ref, const uint8_t* d_dist, uint32_t w, uint32_t h, bool ref_pyramid_ready) {
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+    if (c->use_graph && c->rg_dbg_scale < 0 && !g_launch_timer) {
+        LaunchRecorder* rec = new (std::nothrow) LaunchRecorder();
+        if (!rec) return c->fail(SSIMU2_ERR_OOM, "launch recorder");
+        g_launch_recorder = rec;
+        int rc = enqueue_score_launches(c, d_ref, d_dist, w, h, ref_pyramid_ready);
+        g_launch_recorder = nullptr;
+        if (rc == SSIMU2_OK) rc = graph_flush(c, *rec);
+        delete rec;
+        return rc;
+    }
+#endif
+    return enqueue_score_launches(c, d_ref, d_dist, w, h, ref_pyramid_ready);
 }
 
 int check_args(ssimu2_ctx* c, const void* a, const void* b, uint32_t w, uint32_t h) {
@@ -1045,6 +1201,9 @@ void ssimu2_ctx_destroy(ssimu2_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef SSIMU2_INSTRUMENTED_BUILD
+    graph_drop(c);
+#endif
     free_buffers(c);
     (void)hipFree(c->d_result);
     (void)hipHostFree(c->h_result);
@@ -1147,7 +1306,7 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
         for (int sc = 0; sc < p.nscales; ++sc) {
             const size_t n = (size_t)p.w[sc] * p.h[sc];
             const void* in = sc == 0 ? (const void*)c->d_ref_u8 : (const void*)(c->d_lin_ref + p.lin_off[sc]);
-            hipLaunchKernelGGL(k_ref_xyb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in,
+            launch(k_ref_xyb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in,
                                sc == 0, p.w[sc], p.h[sc], c->d_xyb_ref + xyb_off(p, sc));
         }
     }
@@ -1173,7 +1332,7 @@ static int set_reference_impl(ssimu2_ctx* c, const void* ref, uint32_t w, uint32
             build_plans(c, p, c->d_ref_u8, c->d_ref_u8, true, &mp, &fa, &blocks);
             for (int sc = 0; sc < p.nscales; ++sc) mp.dist[sc] = mp.ref[sc];  // second frame unused
             if (blocks > 0)
-                hipLaunchKernelGGL(k_ref_blur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
+                launch(k_ref_blur, dim3(blocks), dim3(MARCH_THREADS), 0, c->stream, mp);
         }
     } else if (c->d_ref_blur) {
         (void)hipFree(c->d_ref_blur);
@@ -1243,10 +1402,10 @@ int ssimu2_score_against_reference_strided(ssimu2_ctx* c, const uint8_t* pixels,
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_stage, pixels, bytes, hipMemcpyHostToDevice, c->stream));
     if (channels == 4 && w % 4 == 0 && row_bytes % 4 == 0)
-        hipLaunchKernelGGL(k_unpack_rgb<true>, dim3((w / 4 + 255) / 256, h), dim3(256), 0, c->stream,
+        launch(k_unpack_rgb<true>, dim3((w / 4 + 255) / 256, h), dim3(256), 0, c->stream,
                            c->d_stage, row_bytes, channels, w, h, c->d_dist_u8);
     else
-        hipLaunchKernelGGL(k_unpack_rgb<false>, dim3((w + 255) / 256, h), dim3(256), 0, c->stream,
+        launch(k_unpack_rgb<false>, dim3((w + 255) / 256, h), dim3(256), 0, c->stream,
                            c->d_stage, row_bytes, channels, w, h, c->d_dist_u8);
     int rc = enqueue_score(c, c->d_ref_u8, c->d_dist_u8, w, h, true);
     if (rc) return rc;

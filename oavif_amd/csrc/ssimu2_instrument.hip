@@ -57,6 +57,15 @@ int ssimu2_instr_set_segment_rows(ssimu2_ctx* c, int rows_scale0, int rows_other
     return SSIMU2_OK;
 }
 
+int ssimu2_instr_use_graph(ssimu2_ctx* c, int enabled, unsigned long long* out_builds, unsigned long long* out_launches) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (c->pending) return c->fail(SSIMU2_ERR_INVALID_ARG, "ssimu2_instr_use_graph: a score is still enqueued");
+    if (enabled >= 0) c->use_graph = enabled != 0;
+    if (out_builds) *out_builds = c->graph_builds;
+    if (out_launches) *out_launches = c->graph_launches;
+    return SSIMU2_OK;
+}
+
 int ssimu2_instr_placed_streams(ssimu2_ctx* c, int* out_n) {
     if (!c || !out_n) return SSIMU2_ERR_INVALID_ARG;
     *out_n = pool_size(c->device);
@@ -323,6 +332,93 @@ int ssimu2_time_blur_stage_rotating(ssimu2_ctx* c, const void* const* d_frames, 
     *out_ms_avg = ms / (float)iters;
     // algorithmic bytes of one launch: every plane element read once and written once
     if (out_bytes_per_launch) *out_bytes_per_launch = 2.0 * (double)xyb_off(p, p.nscales) * sizeof(float);
+    return SSIMU2_OK;
+}
+
+// Every kernel of a score timed where it runs: `iters` scores enqueued through the product's own enqueue_score() while a
+// timing scope is open, so each launch is made with hipExtLaunchKernelGGL and a start / stop event pair -- the kernel's
+// duration as its dispatch packet recorded it (what rocprofv3's kernel trace reads), no packet added between the launches.
+//   d_refs == NULL: reference-cached passes against `d_ref` (set here with ssimu2_set_reference_device), rotating over
+//                   the distorted frames d_dists[0..n-1]   (FIR: pyramid, k_march_refblur, k_finalize;
+//                                                            recursive: k_pyramid_bands_xyb, k_rg_h, k_rg_v, k_finalize)
+//   d_refs != NULL: pair scores of (d_refs[i], d_dists[i])  (FIR: pyramid, k_march, k_finalize;
+//                                                            recursive: the reference's three launches, then the pass's four)
+// out_ms_avg[k] = average milliseconds of the k-th launch of a score, *out_launches = launches per score (<= 8);
+// *out_ms_wall_timed / *out_ms_wall_plain = stream time per score (events around all `iters` scores) of the timed run and
+// of the same run with plain launches: the difference is what the per-launch timestamps cost.
+int ssimu2_time_kernels(ssimu2_ctx* c, const void* d_ref, const void* const* d_refs, const void* const* d_dists, int n,
+                        uint32_t w, uint32_t h, int iters, float* out_ms_avg, int* out_launches, float* out_ms_wall_timed,
+                        float* out_ms_wall_plain) {
+    if (!c) return SSIMU2_ERR_INVALID_ARG;
+    if (!d_dists || n <= 0 || n > 256 || iters <= 0 || iters > 512 || !out_ms_avg || !out_launches)
+        return c->fail(SSIMU2_ERR_INVALID_ARG, "bad frames/iters/out");
+    if (!d_refs && !d_ref) return c->fail(SSIMU2_ERR_INVALID_ARG, "neither a cached reference nor pairs");
+    int rc = check_args(c, d_refs ? d_refs[0] : d_ref, d_dists[0], w, h);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        if (!d_dists[i] || (d_refs && !d_refs[i])) return c->fail(SSIMU2_ERR_INVALID_ARG, "null frame pointer");
+    const bool cached = d_refs == nullptr;
+    if (cached) {
+        if ((rc = ssimu2_set_reference_device(c, d_ref, w, h))) return rc;
+    } else {
+        HIP_TRY(c, hipSetDevice(c->device));
+        if ((rc = ensure_capacity(c, w, h))) return rc;
+        c->have_ref = false;
+    }
+    auto one = [&](int j) {
+        return cached ? enqueue_score(c, c->d_ref_u8, (const uint8_t*)d_dists[j % n], w, h, true)
+                      : enqueue_score(c, (const uint8_t*)d_refs[j % n], (const uint8_t*)d_dists[j % n], w, h, false);
+    };
+    constexpr int kMaxLaunches = 8;
+    const int nev = 2 * kMaxLaunches * iters;
+    hipEvent_t* ev = new (std::nothrow) hipEvent_t[nev];
+    if (!ev) return c->fail(SSIMU2_ERR_OOM, "events");
+    int made = 0;
+    hipError_t e = hipSuccess;
+    for (; made < nev; ++made)
+        if ((e = hipEventCreate(&ev[made])) != hipSuccess) break;
+    double sum[kMaxLaunches] = {0};
+    float wall_timed = 0.f, wall_plain = 0.f;
+    int per_score = 0;
+    if (e == hipSuccess) {
+        const int warm = 2 * n > 24 ? 2 * n : 24;  // clocks and caches as in a run of scores
+        for (int j = 0; j < warm && rc == 0; ++j) rc = one(j);
+        // plain launches first: the stream time per score without the timestamps
+        if (rc == 0) e = hipEventRecord(c->ev0, c->stream);
+        for (int j = 0; j < iters && rc == 0; ++j) rc = one(j);
+        if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+        if (rc == 0 && e == hipSuccess) e = hipEventSynchronize(c->ev1);
+        if (rc == 0 && e == hipSuccess) e = hipEventElapsedTime(&wall_plain, c->ev0, c->ev1);
+        // the same scores with a start / stop event pair on every launch
+        LaunchTimer timer{ev, 0, nev};
+        if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
+        g_launch_timer = &timer;
+        for (int j = 0; j < iters && rc == 0; ++j) rc = one(j);
+        g_launch_timer = nullptr;
+        if (rc == 0 && e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (rc == 0 && e == hipSuccess) e = hipEventElapsedTime(&wall_timed, c->ev0, c->ev1);
+        per_score = timer.n / 2 / iters;
+        if (rc == 0 && e == hipSuccess && (timer.n % (2 * iters) != 0 || per_score < 1 || per_score > kMaxLaunches)) {
+            rc = c->fail(SSIMU2_ERR_INVALID_ARG, "the scores did not all make the same number of launches");
+        }
+        for (int j = 0; j < iters && rc == 0 && e == hipSuccess; ++j)
+            for (int k = 0; k < per_score && e == hipSuccess; ++k) {
+                float ms = 0.f;
+                e = hipEventElapsedTime(&ms, ev[2 * (j * per_score + k)], ev[2 * (j * per_score + k) + 1]);
+                sum[k] += ms;
+            }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->pending = false;
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(SSIMU2_ERR_HIP, "per-kernel timing", e);
+    for (int k = 0; k < per_score; ++k) out_ms_avg[k] = (float)(sum[k] / iters);
+    *out_launches = per_score;
+    if (out_ms_wall_timed) *out_ms_wall_timed = wall_timed / (float)iters;
+    if (out_ms_wall_plain) *out_ms_wall_plain = wall_plain / (float)iters;
     return SSIMU2_OK;
 }
 

@@ -264,6 +264,16 @@ class Ssimu2:
             self._raise(rc)
         return int(n.value)
 
+    def use_graph(self, enabled: bool | None = None):
+        """Instrumented build, the hipGraph experiment (ssimu2_instr_use_graph): submit every score of this context as one
+        graph launch.  None = only read the counters.  -> (graphs built, graph launches) so far."""
+        self._need_instr()
+        b, n = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        rc = self._L.ssimu2_instr_use_graph(self._ctx, -1 if enabled is None else int(bool(enabled)), ctypes.byref(b), ctypes.byref(n))
+        if rc != 0:
+            self._raise(rc)
+        return int(b.value), int(n.value)
+
     def rg_stop_after_scale(self, scale: int) -> None:
         """Instrumented build: the recursive mode keeps the 15 raw planes of `scale` (after the
         horizontal pass and after both passes) downloadable (debug_download what = 4 / 5);
@@ -316,6 +326,32 @@ class Ssimu2:
         if rc != 0:
             self._raise(rc)
         return ms.value, nbytes.value
+
+    KERNEL_NAMES = {(False, True): ("pyramid", "march_refblur", "finalize"), (False, False): ("pyramid", "march", "finalize"),
+                    (True, True): ("convert", "h", "v", "finalize"),
+                    (True, False): ("ref_convert", "ref_h", "ref_v_emit", "convert", "h", "v", "finalize")}
+
+    def time_kernels(self, w: int, h: int, d_dists, iters: int, d_ref: int | None = None, d_refs=None, recursive: bool = False):
+        """ssimu2_time_kernels (instrumented build): every kernel of a score timed where it runs, from its own dispatch packet.
+        `d_ref` = reference-cached passes over the distorted frames `d_dists`; `d_refs` = pair scores of (d_refs[i], d_dists[i]).
+        -> ({launch name: average device ms}, stream ms per score with the timestamps, stream ms per score without).
+        `recursive` names the launches only (the context's blur mode decides what runs)."""
+        self._need_instr()
+        n = len(d_dists)
+        arr = ctypes.c_void_p * n
+        ms = (ctypes.c_float * 8)()
+        nl = ctypes.c_int()
+        wt, wp = ctypes.c_float(), ctypes.c_float()
+        rc = self._L.ssimu2_time_kernels(self._ctx, ctypes.c_void_p(d_ref or 0), arr(*d_refs) if d_refs is not None else None,
+                                         arr(*d_dists), n, w, h, iters, ms, ctypes.byref(nl), ctypes.byref(wt), ctypes.byref(wp))
+        if rc != 0:
+            self._raise(rc)
+        if d_refs is None:
+            self._ref_shape = (h, w, 3)
+        names = self.KERNEL_NAMES[(bool(recursive), d_refs is None)]
+        if nl.value != len(names):   # e.g. a frame with one scale has no pyramid launch
+            names = tuple(f"launch{k}" for k in range(nl.value))
+        return dict(zip(names, (float(ms[k]) for k in range(nl.value)))), float(wt.value), float(wp.value)
 
     def set_segment_rows(self, rows_scale0: int, rows_other_scales: int) -> None:
         self._need_instr()
