@@ -274,6 +274,29 @@ def rank_core_sets(local_world: int, cpus: Optional[Sequence[int]] = None,
     return sets
 
 
+def gpu_slices(cpus: Sequence[int], gpu_cpulists: Sequence[Sequence[int]]) -> List[Optional[List[int]]]:
+    """For every GPU of the node: its slice of the allowed cores `cpus` (in their order) -- the GPUs whose NUMA-local cores
+    meet the allowed set share that intersection in contiguous slices, as if every one of them ran a rank -- or None for a
+    GPU none of whose local cores this process may use (a cpuset that covers another socket only).  One GPU outside the
+    mask does not change the others' slices (it used to drop the whole table to an even split of the allowed
+    cores over all GPUs of the host, which pinned a one-GPU tenant with 16 allowed cores to 2)."""
+    near_of = []
+    for lst in gpu_cpulists:
+        ns = set(lst)
+        near_of.append(tuple(c for c in cpus if c in ns))
+    groups: Dict[tuple, List[int]] = {}
+    for g, near in enumerate(near_of):
+        if near:
+            groups.setdefault(near, []).append(g)
+    out: List[Optional[List[int]]] = [None] * len(near_of)
+    for near, gs in groups.items():
+        per = max(1, len(near) // len(gs))
+        for k, g in enumerate(gs):
+            lo = min(k * per, max(len(near) - 1, 0))
+            out[g] = list(near[lo: lo + per]) or [near[-1]]
+    return out
+
+
 def node_core_sets(local_world: int, procs_per_gpu: int = 1, sysfs: str = "/sys", dev: str = "/dev") -> List[List[int]]:
     """rank_core_sets for this node as it is: sysfs topology, cgroup quota, and the GPUs this job really has.
     Every GPU of the node owns a slice of the cores of its NUMA node (the slice it would get if every GPU of the node
@@ -292,10 +315,15 @@ def node_core_sets(local_world: int, procs_per_gpu: int = 1, sysfs: str = "/sys"
         index = {pci: k for k, (pci, _c) in enumerate(allg)}
         need = -(-local_world // ppg)                      # GPUs this job's ranks sit on
         if len(mine_pci) >= need and all(p_ in index for p_ in mine_pci[:need]):
-            node = rank_core_sets(len(allg), cpus=cpus, gpu_cpulists=[c for _p, c in allg])
+            node = gpu_slices(cpus, [c for _p, c in allg])
+            slices = [node[index[mine_pci[g]]] for g in range(need)]
+            if any(sl is None for sl in slices):
+                # one of THIS job's GPUs has no local core inside the affinity mask: nothing is near it, so the allowed
+                # cores are split among the GPUs the job really has (`need`), not among every GPU of the host
+                slices = rank_core_sets(need, cpus=cpus)
             sets: List[List[int]] = []
             for g in range(need):
-                sl = node[index[mine_pci[g]]]
+                sl = slices[g]
                 k = min(ppg, local_world - g * ppg)
                 sets += rank_core_sets(k, cpus=sl) if k > 1 else [list(sl)]
             if all(sets):

@@ -42,6 +42,55 @@ def query_device(device: int = 0, instrumented: bool = False) -> dict:
     return d.as_dict()
 
 
+class _CtxHolder:
+    """The native context and who still needs it: the Ssimu2 object that created it (`owner`) and every page-locked buffer
+    handed out by host_alloc whose numpy array is still referenced.  ssimu2_ctx_destroy runs when the owner has closed AND
+    the last such array is gone -- closing a scorer never unmaps memory a live array points into."""
+
+    def __init__(self, L, ctx):
+        self.L, self.ctx, self.owner, self.buffers = L, ctx, True, 0
+
+    def release_owner(self):
+        self.owner = False
+        self._maybe_destroy()
+
+    def buffer_gone(self):
+        self.buffers -= 1
+        self._maybe_destroy()
+
+    def _maybe_destroy(self):
+        if not self.owner and self.buffers <= 0 and self.ctx is not None and self.ctx.value:
+            self.L.ssimu2_ctx_destroy(self.ctx)
+            self.ctx = None
+
+
+class _PinnedBuffer:
+    """One allocation of ssimu2_host_alloc as the base object of the numpy array handed to the caller: every view of that
+    array keeps this object alive, and the memory is returned (ssimu2_host_free) when the last of them is gone or when the
+    caller says host_free.  Freed exactly once."""
+
+    def __init__(self, holder: _CtxHolder, ptr: int, nbytes: int):
+        self.holder, self.ptr, self.nbytes, self.freed = holder, ptr, nbytes, False
+        holder.buffers += 1
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def free(self) -> int:
+        if self.freed:
+            return 0
+        self.freed = True
+        rc = 0
+        if self.holder.ctx is not None and self.holder.ctx.value:
+            rc = self.holder.L.ssimu2_host_free(self.holder.ctx, ctypes.c_void_p(self.ptr))
+        self.holder.buffer_gone()
+        return rc
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # interpreter shutdown
+            pass
+
+
 class Ssimu2:
     """One scorer context = one HIP stream + device scratch (not re-entrant)."""
 
@@ -54,23 +103,26 @@ class Ssimu2:
         self.instrumented = bool(instrumented)
         self._L = _lib.instr_lib() if instrumented else _lib.lib()
         self._ctx = ctypes.c_void_p()
+        self._holder = None
         rc = self._L.ssimu2_ctx_create(int(device), ctypes.c_void_p(stream or 0),
                                        ctypes.byref(self._ctx))
         if rc != 0:
             msg = self._L.ssimu2_last_error(None).decode()
             self._ctx = ctypes.c_void_p()
             raise Ssimu2Error(rc, msg or "ssimu2_ctx_create failed")
+        self._holder = _CtxHolder(self._L, ctypes.c_void_p(self._ctx.value))
+        self._pinned = {}   # data address -> weak reference to the _PinnedBuffer behind a host_alloc array
         self.device = device
         if blur is not None and int(blur) != _lib.BLUR_FIR:
             self.set_blur(blur)
 
     def close(self) -> None:
-        if getattr(self, "_ctx", None) and self._ctx.value:
-            for ptr in list(getattr(self, "_pinned", {}).values()):
-                self._L.ssimu2_host_free(self._ctx, ctypes.c_void_p(ptr))
-            self._pinned = {}
-            self._L.ssimu2_ctx_destroy(self._ctx)
+        """The context is unusable from here on.  Page-locked buffers of host_alloc whose arrays are still referenced stay
+        mapped -- and the native context alive underneath them -- until the last such array is dropped."""
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self._ctx = ctypes.c_void_p()
+            self._pinned = {}
+            self._holder.release_owner()
 
     def device_info(self) -> dict:
         """ssimu2_ctx_device_info: the record the context was created with (arch, LDS per CU, PCI bus id, ...)."""
@@ -81,25 +133,31 @@ class Ssimu2:
         return d.as_dict()
 
     def host_alloc(self, shape) -> np.ndarray:
-        """ssimu2_host_alloc: a uint8 array of `shape` in page-locked host memory (uploads from it skip the HIP
-        runtime's staging copy).  Freed by host_free or when the context closes; do not use it afterwards."""
+        """ssimu2_host_alloc: a uint8 array of `shape` in page-locked host memory (uploads from it skip the HIP runtime's
+        staging copy).  The memory belongs to the array: it is returned when the array and all its views are gone, or at
+        host_free(array) -- after which the caller must not touch the array again.  Closing the scorer first is safe (the
+        memory stays mapped while an array points into it).  ssimu2_host_free synchronises the whole device: allocate
+        once per context and reuse, never per score."""
         shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
         n = int(np.prod(shape))
         ptr = ctypes.c_void_p()
         rc = self._L.ssimu2_host_alloc(self._ctx, n, ctypes.byref(ptr))
         if rc != 0:
             self._raise(rc)
-        a = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr.value)).reshape(shape)
-        if not hasattr(self, "_pinned"):
-            self._pinned = {}
-        self._pinned[a.ctypes.data] = ptr.value
+        buf = _PinnedBuffer(self._holder, ptr.value, n)
+        a = np.asarray(buf).reshape(shape)      # a.base chain ends at `buf`
+        import weakref
+        self._pinned[a.ctypes.data] = weakref.ref(buf)
         return a
 
     def host_free(self, a: np.ndarray) -> None:
-        ptr = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
-        if ptr is None:
-            raise ValueError("not a buffer of this context's host_alloc")
-        rc = self._L.ssimu2_host_free(self._ctx, ctypes.c_void_p(ptr))
+        """Return a host_alloc buffer now (a device-wide synchronisation, see host_alloc).  `a` and its views must not be
+        used afterwards."""
+        ref = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        buf = ref() if ref is not None else None
+        if buf is None or buf.freed:
+            raise ValueError("not a (live) buffer of this context's host_alloc")
+        rc = buf.free()
         if rc != 0:
             self._raise(rc)
 

@@ -54,8 +54,10 @@ def work(i):
         while time.time() < stop:
             if s is None or rng.random() < 0.02:      # a fresh context now and then
                 if s is not None:
+                    pins = {}                          # its page-locked buffers go with it
                     s.close()
                 s = oavif_amd.Ssimu2(0)
+                pins = {}
             mode = MODES[int(rng.integers(0, 3))]
             s.set_blur(_lib.BLUR_FIR if mode is None else mode)
             wh = SIZES[int(rng.integers(0, len(SIZES)))]
@@ -68,11 +70,12 @@ def work(i):
                     got = s.compute_ssimu2(ref, d)
                 elif entry == 1:
                     got = s.score_against_reference(d)
-                elif entry == 3:                       # decode-into-pinned, as csrc/oavif_host.c does
-                    pin = s.host_alloc(d.shape)
+                elif entry == 3:                       # decode-into-pinned, as csrc/oavif_host.c does: one buffer per
+                    if pins.get(d.shape) is None:      # context and frame size, reused (ssimu2_host_free synchronises the
+                        pins[d.shape] = s.host_alloc(d.shape)   # whole device: never allocate / free per score)
+                    pin = pins[d.shape]
                     pin[...] = d
                     got = s.score_against_reference(pin)
-                    s.host_free(pin)
                 else:                                  # libavif's RGBA rows with padding behind every row
                     h, w, _ = d.shape
                     rows = np.zeros((h, w * 4 + 24), np.uint8)

@@ -126,6 +126,7 @@ def classify(kit, results):
             worst[m] = max(worst[m], d[m])
         rows.append((name, score, d, min(MODES, key=lambda m: d[m])))
     match = [m for m in MODES if worst[m] <= tol]
+    libm = kit.get("libm_dependent_variants", {})     # variants whose recorded scores depend on the recording host's libm
     ranked = rank_variants(kit, results) if rows else []
     close = [r for r in ranked if r[1] <= tol and r[0] not in MODES]     # variants the scorer does not implement
     if not rows:
@@ -143,7 +144,9 @@ def classify(kit, results):
         verdict = (f"STAGE: no blur mode of the scorer matches, but the checker's variant `{v}` does (every pair within +-{tol}, worst "
                    f"{w_:.4f}): fssimu2 differs from the published algorithm in the {stage.upper()} stage -- {what}.  The HIP scorer does "
                    f"not implement that variant; the oracle does (oracle/ssimu2_oracle.c OR_VAR_*): it is the specification of the change"
-                   + (f" [also within +-{tol}: {', '.join(others)}]" if others else ""))
+                   + (f" [also within +-{tol}: {', '.join(others)}]" if others else "")
+                   + (f" [INDICATIVE ONLY: `{v}` calls the host libm (powf / cbrtf), whose last bits differ between glibc versions; its "
+                      f"scores were recorded with {libm.get('recorded_with', 'an unrecorded libm')}]" if v in libm.get("names", ()) else ""))
     else:
         near = min(MODES, key=lambda m: worst[m])
         v, w_, _, stage = ranked[0]
@@ -189,7 +192,9 @@ def main(argv):
                 if v in vs and base in vs:
                     gaps.append(abs(vs[v] - vs[base]))
             print(f"{v:28s} {meta['stage']:8s} {'[HIP mode] ' if meta.get('implemented_by_the_hip_scorer') else ''}{meta['what']}"
-                  + (f"   (moves the kit's scores by {min(gaps):.4f} .. {max(gaps):.4f} against `{'recursive' if v.startswith('recursive') else 'fir'}`)" if gaps and max(gaps) > 0 else ""))
+                  + (f"   (moves the kit's scores by {min(gaps):.4f} .. {max(gaps):.4f} against `{'recursive' if v.startswith('recursive') else 'fir'}`)" if gaps and max(gaps) > 0 else "")
+                  + ("   [indicative only: host libm, recorded with " + kit["libm_dependent_variants"].get("recorded_with", "?") + "]"
+                     if v in kit.get("libm_dependent_variants", {}).get("names", ()) else ""))
         return 0
     results = {}
     for ln in open(argv[0]):

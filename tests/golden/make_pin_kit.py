@@ -17,6 +17,7 @@ The scores are the checker's, not fssimu2's: parity stays unpinned until somebod
 import hashlib
 import json
 import os
+import platform
 import sys
 
 import numpy as np
@@ -89,6 +90,12 @@ def main():
            "variants_note": "variant_scores[name] per pair: the checker with ONE stage switched to a plausible alternative "
                             "(oracle/ssimu2_oracle.c OR_VAR_*); scripts/pin_blur_mode.py ranks them against fssimu2's scores and "
                             "names the stage of the nearest one",
+           "libm_dependent_variants": {
+               "names": sorted(n for n in orc.PIN_VARIANTS if n.endswith("+srgb_powf") or n.endswith("+cbrt_libm")),
+               "recorded_with": "%s %s" % platform.libc_ver(),
+               "note": "these variants call the host libm's powf / cbrtf, which are not bit-stable across glibc versions: their "
+                       "recorded scores are INDICATIVE (under the recursive modes a last-bit colour difference moves a score by "
+                       "more than the tolerance); tests compare them exactly only on the glibc they were recorded with"},
            "tolerance": 0.01, "pairs": pairs}
     json.dump(doc, open(os.path.join(KIT, "pin_kit.json"), "w"), indent=1)
     for p in pairs:

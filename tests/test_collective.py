@@ -107,6 +107,28 @@ def test_fewer_devices_than_ranks_are_refused_with_and_without_a_rendezvous(tmp_
     assert rcs == [4, 4] and all("1 visible device(s) for 2 ranks" in r["preflight"] for r in recs)
 
 
+def test_the_store_exchange_also_works_under_torch_distributed_run(tmp_path, hip_lib):
+    """The driver starts N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`: there the rendezvous store is the
+    elastic agent's (every worker is a client of it, TORCHELASTIC_USE_AGENT_STORE), not one rank 0 hosts.  The same
+    open_group must exchange, judge, open the group and confirm under that launcher too -- and refuse under it."""
+    env = dict(os.environ, FAKE_BUS="0000:05:00.0,0000:15:00.0", CLAIM_BACKEND="nccl", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = tmp_path / "tr"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), WORKER, str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    recs = [json.load(open(f"{out}.rank{r}")) for r in range(2)]
+    assert all(r["rc"] == 0 and r["collective"]["problems"] == [] and r["collective"]["distinct_devices"] == 2 for r in recs)
+    assert "confirmed by one all_gather" in recs[0]["collective"]["gathered_through"] and _init_called(out, 2) == [True, True]
+    out = tmp_path / "tr_dup"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), WORKER, str(out)], capture_output=True, text=True, timeout=300,
+                       env=dict(env, FAKE_BUS="0000:05:00.0,0000:05:00.0"))
+    assert p.returncode != 0 and ("exitcode  : 4" in p.stderr or "exitcode: 4" in p.stderr), p.stderr[-3000:]
+    assert _init_called(out, 2) == [False, False]
+
+
 def test_rules_on_hand_made_records():
     from oavif_amd import collective
     mk = lambda rank, host, bus: {"rank": rank, "host": host, "pci_bus_id": bus}

@@ -95,3 +95,50 @@ def test_pinned_buffers_score_like_pageable_ones(hip_lib, oracle):
                 s.host_free(rgba)                                  # already returned
             assert abs(want - oracle.compute_ssimu2(ref, dst, oracle.BLUR_FIR if blur == _lib.BLUR_FIR else oracle.BLUR_IIR)) <= 1e-3
         # the remaining buffers are released with the context
+
+
+def test_pinned_arrays_outlive_the_scorer_that_made_them():
+    """closing a scorer (close, __exit__, __del__) while a host_alloc array is still referenced must not unmap the
+    memory under it.  The array owns its buffer (its base chain ends at the allocation), the native context is destroyed only
+    when the scorer has closed AND the last such array is gone, and a buffer is returned exactly once.  CPU: the native calls
+    are recorded by a stand-in library."""
+    import ctypes
+    import gc
+    import numpy as np
+    from oavif_amd import scorer
+
+    class Lib:
+        def __init__(self):
+            self.freed, self.destroyed = [], []
+
+        def ssimu2_host_free(self, ctx, p):
+            assert not self.destroyed            # never after the context is gone
+            self.freed.append(p.value)
+            return 0
+
+        def ssimu2_ctx_destroy(self, ctx):
+            self.destroyed.append(ctx.value)
+
+    mem = (ctypes.c_uint8 * 96)()
+    lib = Lib()
+    holder = scorer._CtxHolder(lib, ctypes.c_void_p(4242))
+    a = np.asarray(scorer._PinnedBuffer(holder, ctypes.addressof(mem), 48)).reshape(4, 4, 3)
+    b = np.asarray(scorer._PinnedBuffer(holder, ctypes.addressof(mem) + 48, 48))
+    view = a[1:3]
+    holder.release_owner()                       # Ssimu2.close()
+    assert lib.destroyed == [] and lib.freed == []          # both arrays alive: nothing unmapped, the context stays
+    a[...] = 7
+    del a
+    gc.collect()
+    assert lib.freed == [] and int(view.sum()) == 7 * 24    # a view keeps the buffer
+    del view
+    gc.collect()
+    assert lib.freed == [ctypes.addressof(mem)] and lib.destroyed == []
+    base = b.base
+    while not isinstance(base, scorer._PinnedBuffer):
+        base = base.base
+    assert base.free() == 0 and base.free() == 0            # explicit return (host_free), then nothing more to do
+    assert lib.freed == [ctypes.addressof(mem), ctypes.addressof(mem) + 48] and lib.destroyed == [4242]
+    del b, base
+    gc.collect()
+    assert len(lib.freed) == 2 and lib.destroyed == [4242]  # returned exactly once, destroyed exactly once

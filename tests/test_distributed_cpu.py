@@ -479,3 +479,31 @@ open(out, "wb").write(b"x" * (100 * n + (7 if tol else 0)))
     assert args.exec_oavif and args.oavif_path == str(fake)
     with pytest.raises(SystemExit):
         batch.parse_cli([str(tmp_path), str(tmp_path / "r.csv"), "--exec"])
+
+
+def test_a_cpuset_of_one_socket_does_not_shrink_a_tenants_slice(tmp_path, monkeypatch):
+    """a cpuset-restricted container that was handed GPUs and cores of ONE socket.  Four of the host's eight GPUs
+    have no local core inside the mask; that must not drop the placement to an even split of the allowed cores over all eight
+    GPUs (a one-GPU tenant with 16 allowed cores ended up pinned to 2)."""
+    from oavif_amd import hostinfo
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: None)
+    sysfs, dev = _fake_host(tmp_path / "a", ["0000:f1:00.0"], {"0000:f1:00.0"})           # the fourth GPU of NUMA node 1
+    # the mask covers node 1 only (cpus 64-127 + their SMT siblings): the GPU keeps its quarter of node 1, both threads of 16 cores
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(64, 128)) + list(range(192, 256)))
+    mine = hostinfo.node_core_sets(1, sysfs=sysfs, dev=dev)
+    assert len(mine) == 1 and len(mine[0]) == 32 and hostinfo.cpu_numa_nodes(mine[0], sysfs) == [1]
+    assert set(mine[0]) == set(range(112, 128)) | set(range(240, 256))
+    # sixteen allowed cores of node 1, one GPU: the tenant gets its share of THOSE (a quarter: four GPUs hang off node 1), not 2 of 16
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(64, 80)))
+    mine = hostinfo.node_core_sets(1, sysfs=sysfs, dev=dev)
+    assert mine == [list(range(76, 80))]
+    # the mask covers the OTHER socket only: nothing is near the job's GPU, so the allowed cores go to the GPUs the job really
+    # has (one), not to an eighth each
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(0, 16)))
+    assert hostinfo.node_core_sets(1, sysfs=sysfs, dev=dev) == [list(range(0, 16))]
+    assert hostinfo.node_core_sets(2, procs_per_gpu=2, sysfs=sysfs, dev=dev) == [list(range(0, 8)), list(range(8, 16))]
+    # gpu_slices itself: GPUs outside the mask are None, the others share their intersection
+    sl = hostinfo.gpu_slices(list(range(64, 80)), [list(range(0, 64))] * 4 + [list(range(64, 128))] * 4)
+    assert sl[:4] == [None] * 4 and sl[4:] == [list(range(64, 68)), list(range(68, 72)), list(range(72, 76)), list(range(76, 80))]

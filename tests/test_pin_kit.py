@@ -63,6 +63,10 @@ def test_checker_reproduces_the_recorded_variant_scores(doc, oracle):
     """Round 5: every entry of the stage-variant catalogue (oracle PIN_VARIANTS) on the small committed pairs; the
     catalogue in the kit is the checker's, entry for entry; the three blur modes' variant scores ARE the mode scores."""
     assert set(doc["variants"]) == set(oracle.PIN_VARIANTS) and len(doc["variants"]) == 22
+    import platform
+    libm = doc["libm_dependent_variants"]
+    assert libm["names"] == ["fir+cbrt_libm", "fir+srgb_powf", "recursive+cbrt_libm", "recursive+srgb_powf"] and "INDICATIVE" in libm["note"]
+    same_libm = libm["recorded_with"] == "%s %s" % platform.libc_ver()
     assert {v["stage"] for v in doc["variants"].values()} == {"blur", "pyramid", "colour", "maps"}
     assert [n for n, v in doc["variants"].items() if v["implemented_by_the_hip_scorer"]] == ["fir", "recursive", "recursive_fma"]
     for p in doc["pairs"]:
@@ -74,6 +78,11 @@ def test_checker_reproduces_the_recorded_variant_scores(doc, oracle):
         ref, dst = _pixels(p)
         for v in doc["variants"]:
             got = oracle.pin_variant_score(ref, dst, v, omp=True)
+            if v in libm["names"] and not same_libm:
+                # powf / cbrtf of another glibc may differ in the last bit, and the recursion amplifies that:
+                # indicative entries, compared loosely here (exactly on the glibc they were recorded with)
+                assert abs(got - p["variant_scores"][v]) < (0.5 if v.startswith("recursive") else 0.02), (name, v, got)
+                continue
             assert abs(got - p["variant_scores"][v]) < 1e-9, (name, v, got)
     # variant 0 is the oracle proper, bit for bit; contradictory or misplaced bits are refused
     p = doc["pairs"][3]
