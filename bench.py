@@ -446,6 +446,9 @@ def main() -> int:
                     help="independent scorer contexts (HIP streams) the steps are dealt over")
     ap.add_argument("--pairs", type=int, default=8,
                     help="distinct (ref, dist) pairs per scorer context the steps rotate over")
+    ap.add_argument("--no-by-resolution", action="store_true",
+                    help="skip the by_resolution extra (512x512 ... 7680x4320): the rocprofv3 kernel-trace of a recorded round "
+                         "uses this, so that its per-kernel averages are averages over 3840x2160 launches only")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
@@ -899,7 +902,7 @@ def main() -> int:
             out["recursive_blur_mode"]["kernels"] = {"error": str(e)[:200]}
 
         # ---- the named resolutions (north_star): 512^2, 1080p, 4K, 8K -- N = 1 only ----
-        if world == 1 and (w, h) == (W, H):
+        if world == 1 and (w, h) == (W, H) and not args.no_by_resolution:
             try:
                 t_br = time.perf_counter()
                 out["by_resolution"] = {"sizes": by_resolution(local_rank, t_ref, t_dst, scorers),

@@ -12,8 +12,9 @@ tail -2 $OUT/smoke.log
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -4 $OUT/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp
-# per-kernel durations with the scores of one stream never overlapping (two streams stretch them)
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 512 --warmup 64 --no-cpu-baseline --streams 1 > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
+# per-kernel durations with the scores of one stream never overlapping (two streams stretch them); 3840x2160 launches only
+# (--no-by-resolution: the other sizes of the line's by_resolution extra would be averaged into the same kernel names)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 512 --warmup 64 --no-cpu-baseline --streams 1 --no-by-resolution > $OUT/prof.log 2>&1; echo "rocprof stats rc=$?"
 cd $GRAFT_REPO_ROOT
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cut -c1-150 $OUT/kernel_stats.csv

@@ -5,9 +5,13 @@
 #
 #   scripts/gpu_scale.sh [TAG] [IMAGES] [STEPS]        (repo root; TAG default "scale", IMAGES 256, STEPS 400)
 #
-# For N in 1 2 4 8 (as far as the node has devices): `bench.py --gpus N` (one process per GPU over RCCL, as the
-# driver launches it) and the batch driver over IMAGES synthetic 1920x1080 PNGs (python -m oavif_amd.batch, the
-# scripts/measure.py counterpart: images dealt largest first, one RCCL all_gather of the records).  Every run's
+# For N in 1 2 4 8 (as far as the node has devices): the BARE commands `python3 bench.py --gpus N` and `python3 -m
+# oavif_amd.batch --gpus N ...` (one process per GPU over RCCL; the command starts its own ranks, oavif_amd/launch.py --
+# `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N` runs the
+# same ranks; which of the two forms a driver uses is the driver's business, both are tested) over IMAGES synthetic
+# 1920x1080 PNGs for the batch (the scripts/measure.py counterpart: images dealt largest first, one RCCL all_gather of
+# the records).  The environment is handed to the ranks as it is: nothing is set here (HSA_ENABLE_IPC_MODE_LEGACY: see
+# profiles/r06_ipc_mode_probe.txt and DESIGN.md section 6).  Every run's
 # JSON carries its `collective` record (backend, world size, per rank the device / PCI bus id / NUMA node / pinned
 # cores, RCCL version); a run whose ranks share a GPU exits with rc 4 and is recorded as refused.
 # Output: gpurun_out/TAG/*.json and profiles/scale.json (scripts/make_scale_json.py: MP/s, speed-up over N = 1,
@@ -20,7 +24,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-export HSA_ENABLE_IPC_MODE_LEGACY=0
 NDEV=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 echo "devices visible: $NDEV" | tee "$OUT/devices.txt"
 IMG=/tmp/oavif_scale_imgs_$$
@@ -43,28 +46,15 @@ for i in range($IMAGES):
         f = synth.distort(synth.distort(f, "blur", 2), "noise", (i // 4) % 2, seed=i)
     Image.fromarray(f).save("$IMG/img%03d.png" % i, compress_level=1)
 PY
-PORT=29700
 for N in 1 2 4 8; do
   if [ "$N" -gt "$NDEV" ]; then echo "N=$N skipped: $NDEV device(s)"; continue; fi
-  PORT=$((PORT + 1))
   echo "== bench.py --gpus $N"
-  if [ "$N" -eq 1 ]; then
-    timeout -k 10 900 python3 bench.py --gpus 1 --steps "$STEPS" --warmup 50 --no-cpu-baseline > "$OUT/bench_n$N.json" 2> "$OUT/bench_n$N.err"
-  else
-    timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT \
-      bench.py --gpus "$N" --steps "$STEPS" --warmup 50 > "$OUT/bench_n$N.json" 2> "$OUT/bench_n$N.err"
-  fi
+  EXTRA=""; [ "$N" -eq 1 ] && EXTRA="--no-cpu-baseline"
+  timeout -k 10 900 python3 bench.py --gpus "$N" --steps "$STEPS" --warmup 50 $EXTRA > "$OUT/bench_n$N.json" 2> "$OUT/bench_n$N.err"
   echo "rc=$?" | tee "$OUT/bench_n$N.rc"
-  PORT=$((PORT + 1))
   echo "== batch of $IMAGES x 1080p on $N GPU(s)"
-  if [ "$N" -eq 1 ]; then
-    OAVIF_GATHER_ALWAYS=1 timeout -k 10 1800 python3 -m oavif_amd.batch "$IMG" "$OUT/batch_n$N.csv" --out-dir "/tmp/oavif_scale_out_$$_$N" \
-      --collective-json "$OUT/batch_n$N.json" > "$OUT/batch_n$N.log" 2> "$OUT/batch_n$N.err"
-  else
-    timeout -k 10 1800 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT \
-      -m oavif_amd.batch "$IMG" "$OUT/batch_n$N.csv" --out-dir "/tmp/oavif_scale_out_$$_$N" \
-      --collective-json "$OUT/batch_n$N.json" > "$OUT/batch_n$N.log" 2> "$OUT/batch_n$N.err"
-  fi
+  OAVIF_GATHER_ALWAYS=1 timeout -k 10 1800 python3 -m oavif_amd.batch --gpus "$N" "$IMG" "$OUT/batch_n$N.csv" --out-dir "/tmp/oavif_scale_out_$$_$N" \
+    --collective-json "$OUT/batch_n$N.json" > "$OUT/batch_n$N.log" 2> "$OUT/batch_n$N.err"
   echo "rc=$?" | tee "$OUT/batch_n$N.rc"
   grep -E "Images:|Ranks|Total wall|Throughput:|Average passes|Collective:" "$OUT/batch_n$N.log"
   rm -rf "/tmp/oavif_scale_out_$$_$N"
