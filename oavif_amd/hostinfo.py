@@ -313,19 +313,24 @@ def node_core_sets(local_world: int, procs_per_gpu: int = 1, sysfs: str = "/sys"
     mine_pci = visible_gpus(sysfs, dev)
     if allg and mine_pci:
         index = {pci: k for k, (pci, _c) in enumerate(allg)}
-        need = -(-local_world // ppg)                      # GPUs this job's ranks sit on
-        if len(mine_pci) >= need and all(p_ in index for p_ in mine_pci[:need]):
+        need = -(-local_world // ppg)                      # GPUs this job's ranks ask for
+        have = min(need, len(mine_pci))                    # ... and really have: with fewer (a gloo rehearsal on a smaller box)
+        if have >= 1 and all(p_ in index for p_ in mine_pci[:have]):   # rank r sits on device (r // ppg) % have, as the entry points place it
             node = gpu_slices(cpus, [c for _p, c in allg])
-            slices = [node[index[mine_pci[g]]] for g in range(need)]
+            slices = [node[index[mine_pci[g]]] for g in range(have)]
             if any(sl is None for sl in slices):
                 # one of THIS job's GPUs has no local core inside the affinity mask: nothing is near it, so the allowed
-                # cores are split among the GPUs the job really has (`need`), not among every GPU of the host
-                slices = rank_core_sets(need, cpus=cpus)
-            sets: List[List[int]] = []
-            for g in range(need):
-                sl = slices[g]
-                k = min(ppg, local_world - g * ppg)
-                sets += rank_core_sets(k, cpus=sl) if k > 1 else [list(sl)]
+                # cores are split among the GPUs the job really has, not among every GPU of the host
+                slices = rank_core_sets(have, cpus=cpus)
+            on_gpu: List[List[int]] = [[] for _ in range(have)]
+            for r in range(local_world):
+                on_gpu[(r // ppg) % have].append(r)
+            sets: List[List[int]] = [[] for _ in range(local_world)]
+            for g in range(have):
+                k = len(on_gpu[g])
+                parts = rank_core_sets(k, cpus=slices[g]) if k > 1 else [list(slices[g])]
+                for r, part in zip(on_gpu[g], parts):
+                    sets[r] = part
             if all(sets):
                 if quota is not None:
                     share = max(1, int(quota / local_world + 0.5))

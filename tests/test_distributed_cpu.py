@@ -507,3 +507,26 @@ def test_a_cpuset_of_one_socket_does_not_shrink_a_tenants_slice(tmp_path, monkey
     # gpu_slices itself: GPUs outside the mask are None, the others share their intersection
     sl = hostinfo.gpu_slices(list(range(64, 80)), [list(range(0, 64))] * 4 + [list(range(64, 128))] * 4)
     assert sl[:4] == [None] * 4 and sl[4:] == [list(range(64, 68)), list(range(68, 72)), list(range(72, 76)), list(range(76, 80))]
+
+
+def test_ranks_that_share_a_gpu_in_a_rehearsal_still_pin_near_it(tmp_path, monkeypatch):
+    """Round 6 (profiles/r06_bench_n4_gloo_bare_rehearsal.json showed it): four ranks of a gloo rehearsal on a box with ONE
+    GPU -- rank r uses device r % 1 -- were pinned to cpus 0-3 / 4-7 / ... of NUMA node 0 although the GPU hangs off node 1:
+    with fewer GPUs than ranks the placement fell back to "GPU 0 of the node".  Rank r now takes its part of the slice of
+    the GPU it really uses."""
+    from oavif_amd import hostinfo
+    monkeypatch.setattr(hostinfo, "allowed_cpus", lambda: list(range(256)))
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 16.0)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    sysfs, dev = _fake_host(tmp_path / "a", ["0000:8b:00.0"], {"0000:8b:00.0"})           # the first GPU of NUMA node 1
+    sets = hostinfo.node_core_sets(4, sysfs=sysfs, dev=dev)
+    assert sets == [list(range(64, 68)), list(range(68, 72)), list(range(72, 76)), list(range(76, 80))]   # one thread per core
+    assert all(hostinfo.cpu_numa_nodes(x, sysfs) == [1] for x in sets)                    # every rank on the GPU's node
+    assert set(sum(sets, [])) <= set(range(64, 80)) | set(range(192, 208))                # inside that GPU's own slice
+    # two GPUs, four ranks: ranks 0 and 2 near the first, 1 and 3 near the second (device = rank % 2)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    sysfs2, dev2 = _fake_host(tmp_path / "b", ["0000:8b:00.0", "0000:0a:00.0"], {"0000:8b:00.0", "0000:0a:00.0"})
+    sets = hostinfo.node_core_sets(4, sysfs=sysfs2, dev=dev2)
+    assert [hostinfo.cpu_numa_nodes(x, sysfs2) for x in sets] == [[1], [0], [1], [0]] and len(set(sum(sets, []))) == 16
