@@ -2,7 +2,9 @@
 """bench.py -- SSIMULACRA2 scorer throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: the command starts its own N ranks, one per GPU -- oavif_amd/launch.py -- unless a launcher has announced a
+     world: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`
+     runs the same ranks)
 
 A *step* is one pass of the hot path over one batch of synthetic input: one SSIMULACRA2
 score of one (ref, dist) pair of 3840x2160 8-bit RGB frames (BASELINE.json configs[1],
@@ -29,14 +31,20 @@ Extra objects on the JSON line:
   cpu_baseline -- the repo's CPU oracle ("port"; the reference's Zig+fssimu2 path cannot be
                   built: no Zig, fssimu2 source absent) timed on this host, rank 0, N = 1 only.
   collective   -- what the process group really was (oavif_amd/collective.py): backend, world size, and per
-                  rank the host, HIP device index, PCI bus id, NUMA node and pinned cores, gathered over the
-                  job's own process group (device tensors through RCCL when the backend is nccl; at N = 1 a
-                  process group of one rank is opened for it after the timed region).  The run exits non-zero
-                  (rc 4) when two RCCL ranks report one GPU or the host shows fewer devices than ranks.
+                  rank the host, HIP device index, PCI bus id, NUMA node, pinned cores and the HSA_* / HIP_* / ROCR_* /
+                  NCCL_* / RCCL_* variables it ran under, exchanged through the rendezvous store BEFORE any communicator
+                  exists and confirmed by one all_gather over the job's process group (device tensors through RCCL when the
+                  backend is nccl; at N = 1 a process group of one rank is opened for it after the timed region).  The run
+                  exits non-zero (rc 4, every rank, no communicator ever created) when two RCCL ranks report one GPU or the
+                  host shows fewer devices than ranks; rc 5 with RCCL's message when the process group cannot be opened.
+  by_resolution -- N = 1: the named resolutions (512x512, 1920x1080, 3840x2160, 7680x4320), each HBM-fed: FIR
+                  pair scoring on two contexts / one stream with the W-model fraction, the recursive cached pass, and every
+                  kernel's own duration beside the stream time of a score.
   per_rank_own_ms_per_step -- N > 1 only: each rank's own work per step up to its synchronize, before the closing
                   barrier (median block); `ms_per_step` is the max over ranks of the whole block, so a slow rank shows.
   default_search_mode -- throughput of the mode the SEARCH path runs by default (the published recursion, one
-                  cached-reference pass per probe), beside `value` (FIR pair scoring, two contexts).
+                  cached-reference pass per probe), beside `value` (FIR pair scoring, two contexts); its per-kernel times
+                  (recursive_blur_mode.kernels) are measured by this run: dispatch-packet timestamps of the instrumented build.
 """
 from __future__ import annotations
 

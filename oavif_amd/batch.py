@@ -16,7 +16,8 @@ and number formats (measure.py:178-206), the summary statistics (measure.py:209-
 only when its quantizer is the chosen one (main.zig:109-113).
 
     python -m oavif_amd.batch IMAGES_DIR [OAVIF_PATH] OUTPUT_CSV [--tolerance T] [--keep]
-    python -m torch.distributed.run --nproc-per-node 8 -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV
+    python -m oavif_amd.batch --gpus 8 IMAGES_DIR OUTPUT_CSV        (one command, as measure.py is: starts its own 8 ranks)
+    python -m torch.distributed.run --nproc-per-node 8 -m oavif_amd.batch IMAGES_DIR OUTPUT_CSV     (the same ranks under a launcher)
 
 The positional arguments are measure.py's (measure.py:111-123: images_dir oavif_path output_csv),
 so an existing invocation keeps working; OAVIF_PATH is accepted and not used (the search runs in
@@ -577,6 +578,7 @@ def main(argv=None) -> int:
         print(f"Collective: backend {coll['backend']}, world {coll['world_size']}, {coll['distinct_devices']} distinct device(s): "
               + "; ".join(f"rank {r_.get('rank')} -> GPU {r_.get('device')} at {r_.get('pci_bus_id')} (NUMA {r_.get('numa_node')})"
                           for r_ in coll["ranks"]))
+        print(f"Collective record exchanged through: {coll['gathered_through']}")
         if args.collective_json:
             import json
             ok_n = sum(1 for r_ in results if r_.status == "ok")

@@ -76,6 +76,19 @@ def test_batch_of_1080p_pngs_two_ranks_equals_one_rank(tmp_path):
     assert "[rank 0]" in p2.stderr and "[rank 1]" in p2.stderr
     # the "N passes" phrase measure.py parses (measure.py:27) is on every per-image line
     assert p2.stderr.count(" passes)") >= 16
+    # round 6: the same job as ONE bare command, as measure.py is one command -- `--gpus 1 --procs-per-gpu 2`: the driver
+    # starts its own two ranks (oavif_amd/launch.py), relays rank 0's summary and leaves with their code
+    three = tmp_path / "three.csv"
+    env3 = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p3 = subprocess.run([sys.executable, "-m", "oavif_amd.batch", "--gpus", "1", "--procs-per-gpu", "2", str(img_dir), str(three),
+                         "--workers", "4", "--out-dir", str(tmp_path / "out3")],
+                        env=env3, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p3.returncode == 0, p3.stderr[-2000:]
+    assert "oavif_amd.batch: launching 2 ranks" in p3.stderr
+    h3, r3 = _rows(three)
+    assert h3 == h1 and r3 == r1
+    assert "Ranks (GPUs): 2" in p3.stdout and "Images: 16 ok" in p3.stdout and "ranks per GPU: 2" in p3.stdout
+    assert "the rendezvous store" in p3.stdout or "Collective: backend gloo, world 2" in p3.stdout
 
 
 def test_record_gather_runs_through_rccl_single_rank(tmp_path):
