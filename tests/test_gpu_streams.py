@@ -76,3 +76,54 @@ def test_a_released_stream_is_reused_and_extra_contexts_still_work(hip_lib):
             c.close()
     with Ssimu2(0) as s:
         assert s.compute_ssimu2(ref, dst) == want
+
+
+def test_per_kernel_timestamps_add_up_to_the_stream_time_and_the_graph_form_keeps_the_bits(hip_lib):
+    """Round 6's two instrumented-build hooks, on the device.  ssimu2_time_kernels: every launch of the library's own enqueue
+    path with a start / stop event pair -- the launches are the expected ones, in order, every duration positive, and their
+    sum is the stream time of a score (no more than 3 % above the plain-launch stream time, not below 85 % of it: the rest
+    is what the launches wait between them).  ssimu2_instr_use_graph: the launches of a score as ONE graph launch -- one
+    graph built per context and shape, one graph launch per score, the exact bits of the plain form (the measured outcome,
+    slower everywhere, is profiles/r06_graph_ab.log: the product library does not have this path)."""
+    import torch
+    from oavif_amd import Ssimu2, _lib
+    w, h = 1920, 1080
+    frames = []
+    for k in range(6):
+        r = synth.make_ref(w, h, 40 + k)
+        frames.append((torch.from_numpy(r).cuda(), torch.from_numpy(synth.distort(r, "blockq", 1 + k % 3)).cuda()))
+    refs, dsts = [a.data_ptr() for a, _ in frames], [b.data_ptr() for _, b in frames]
+    for blur, cached, names in ((_lib.BLUR_FIR, False, ("pyramid", "march", "finalize")),
+                                (_lib.BLUR_FIR, True, ("pyramid", "march_refblur", "finalize")),
+                                (_lib.BLUR_RECURSIVE, True, ("convert", "h", "v", "finalize")),
+                                (_lib.BLUR_RECURSIVE, False, ("ref_convert", "ref_h", "ref_v_emit", "convert", "h", "v", "finalize"))):
+        with Ssimu2(0, instrumented=True, blur=blur) as c:
+            if cached:
+                st, wall_t, wall_p = c.time_kernels(w, h, dsts, 60, d_ref=refs[0], recursive=blur != _lib.BLUR_FIR)
+            else:
+                st, wall_t, wall_p = c.time_kernels(w, h, dsts, 60, d_refs=refs, recursive=blur != _lib.BLUR_FIR)
+            assert tuple(st) == names, st
+            assert all(v > 0.001 for v in st.values())
+            total = sum(st.values())
+            print(f"blur {blur} cached {cached}: kernels {total * 1e3:.1f} us of {wall_p * 1e3:.1f} us of stream time per score")
+            assert 0.85 * wall_p <= total <= 1.03 * wall_p, (st, wall_p)
+            assert wall_t >= 0.97 * wall_p                       # the timestamps cost something, never nothing
+
+            def scores():
+                out = []
+                if cached:
+                    c.set_reference_device(refs[0], w, h)
+                for i in range(6):
+                    if cached:
+                        c.enqueue_against_reference_device(dsts[i])
+                    else:
+                        c.enqueue_device(refs[i], dsts[i], w, h)
+                    out.append(c.wait())
+                return out
+            plain = scores()
+            b0, n0 = c.use_graph(True)
+            graph = scores()
+            b1, n1 = c.use_graph(False)
+            assert graph == plain                                 # same kernels, same arguments, same order: same bits
+            assert b1 - b0 == 1 and n1 - n0 == 6                  # one graph for the shape, one launch per score
+            assert scores() == plain and c.use_graph(None) == (b1, n1)
