@@ -446,7 +446,8 @@ def main() -> int:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         return cpu_baseline_child(sys.argv[2:])
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: 1, or the world a launcher announced)")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -467,6 +468,8 @@ def main() -> int:
     # its own last stdout line and leaves with the first non-zero child code (oavif_amd/launch.py; a refusal stays rc 4).
     # Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks run the same code.
     from oavif_amd import launch
+    if args.gpus is None:   # not asked for: one GPU, or whatever world a launcher (torch.distributed.run) announced
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if launch.needs_self_launch(args.gpus):
         return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, label="bench.py")
 
