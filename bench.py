@@ -407,35 +407,32 @@ def measure_cpu_baseline(w, h, mp):
 
 
 def single_rank_collective(local_rank: int) -> dict:
-    """N = 1: the `collective` record still travels through RCCL -- a process group of ONE rank on backend "nccl"
-    (device_id = this GPU), the same all_gather of device tensors the N > 1 job starts with.  Opened after the timed
-    region so that RCCL's own streams cannot touch the measurement; bounded by a 60 s rendezvous timeout; any failure
-    is recorded, not raised (the throughput line does not depend on it)."""
-    import datetime
-    import socket
+    """N = 1: the `collective` record still travels the way an N > 1 job's does -- collective.open_group with a world of ONE
+    rank on backend "nccl": the record through the rendezvous store first, then the RCCL process group opened on that store
+    (device_id = this GPU, the communicator created eagerly) and the record confirmed by the all_gather of device tensors;
+    then the other two collectives of an N > 1 line (all_reduce MAX, barrier).  Opened after the timed region so that RCCL's
+    own streams cannot touch the measurement; bounded by a 60 s timeout; any failure is recorded, not raised (the
+    throughput line does not depend on it)."""
     import torch
     import torch.distributed as dist
-    from oavif_amd import collective
+    from oavif_amd import collective, launch
     me = collective.rank_record(0, local_rank, local_rank, pinned=None)
     if os.environ.get("OAVIF_BENCH_COLLECTIVE", "1") == "0":
         return collective.describe("none", 1, [me], "not gathered (OAVIF_BENCH_COLLECTIVE=0)")
     try:
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=60))
-        try:
-            recs = collective.gather(me, torch.device("cuda", local_rank))
-            t_ = torch.tensor([1.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # the other collective of an N > 1 line (max over ranks)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            dist.destroy_process_group()
-        bad = collective.problems(recs, "nccl", 1, 1, torch.cuda.device_count())
-        return collective.describe("nccl", 1, recs, "an RCCL process group of one rank (device tensors), opened after the "
-                                                   "timed region", bad)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(launch.free_port())
+        coll, rc_ = collective.open_group(0, local_rank, local_rank, "nccl", 1, 1, pinned=None, label="bench.py", timeout_s=60.0)
+        coll["gathered_through"] += "; an RCCL process group of one rank, opened after the timed region"
+        if rc_ == 0:
+            try:
+                t_ = torch.tensor([1.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)      # the other collective of an N > 1 line (max over ranks)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                dist.destroy_process_group()
+        return coll
     except Exception as e:
         c = collective.describe("nccl", 1, [me], "not gathered: the single-rank RCCL group failed")
         c["error"] = f"{type(e).__name__}: {str(e)[:300]}"

@@ -122,17 +122,17 @@ void ssimu2_ctx_destroy(ssimu2_ctx* ctx);
    which of the two it follows is not known:
      SSIMU2_BLUR_FIR        (default; the THROUGHPUT mode) the 9-tap impulse response of the
                             published sigma-1.5 recursive Gaussian, zero padding, fused kernels --
-                            what bench.py's `value` measures: 0.152 ms per 4K score with two contexts in
-                            flight, 0.173 on one (profiles/r06_bench.json; by size, one context / two:
-                            512x512 29 / 18 us, 1920x1080 69 / 44 us, 7680x4320 0.63 / 0.61 ms);
+                            what bench.py's `value` measures: 0.156 ms per 4K score with two contexts in
+                            flight, 0.176 on one (profiles/r06_bench.json; by size, one context / two:
+                            512x512 28 / 18 us, 1920x1080 68 / 45 us, 7680x4320 0.65 / 0.63 ms);
      SSIMU2_BLUR_RECURSIVE  (the CONSERVATIVE-PARITY mode) the published recursion itself (libjxl
                             FastGaussian: three second-order sections, products rounded to fp32
                             first, horizontal then vertical), operation for operation, planes
                             bit-identical to the CPU checker's.  0.36 ms per 4K pass against a
                             reference set with ssimu2_set_reference (whose XYB planes, blur(x) and
                             blur(x*x) are then cached, so a pass recurses 9 of the 15 planes),
-                            0.69 ms for a pair score (profiles/r06_bench.json; passes at 512x512 /
-                            1920x1080 / 7680x4320: 0.072 / 0.155 / 1.32 ms).  Both modes are checked
+                            0.70 ms for a pair score (profiles/r06_bench.json; passes at 512x512 /
+                            1920x1080 / 7680x4320: 0.071 / 0.154 / 1.32 ms).  Both modes are checked
                             against this repository's CPU checker only: parity against fssimu2 itself
                             is UNPINNED (its source is not available here).  This is the mode
                             the search path runs by default (the Zig shim, the CLI mirror, the batch

@@ -185,6 +185,7 @@ struct ssimu2_ctx {
     int seg_rows_tail_override = 0;
     bool cache_ref_blur = true;
     int rg_dbg_scale = -1;  // recursive mode: keep that scale's 15 raw planes (after each pass) downloadable
+#ifdef SSIMU2_INSTRUMENTED_BUILD
     // the hipGraph experiment of the instrumented build (ssimu2_instr_use_graph): one instantiated chain of kernel nodes
     bool use_graph = false;
     hipGraph_t graph = nullptr;
@@ -195,6 +196,7 @@ struct ssimu2_ctx {
     dim3 graph_grid[8], graph_block[8];
     unsigned graph_lds[8];
     unsigned long long graph_builds = 0, graph_launches = 0;
+#endif
 
     int fail(int code, const char* what, hipError_t e = hipSuccess) {
         char buf[256];

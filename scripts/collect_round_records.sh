@@ -10,7 +10,7 @@ cp $O/valu_rate.txt profiles/${TAG}_valu_rate.txt
 cp $O/pmc_calib_summary.txt profiles/${TAG}_pmc_calib_summary.txt
 cp $O/counters.json profiles/counters.json
 grep '^{' $O/bench.json | tail -1 > profiles/${TAG}_bench.json
-for f in rg_kernel_stats.csv rg_pmc_summary.txt fuzz_3000_recursive.log fuzz_6000_entrypoints.log pinned_ab.json batch_demo.log graph_ab.log; do
+for f in rg_kernel_stats.csv rg_pmc_summary.txt fuzz_3000_recursive.log fuzz_6000_entrypoints.log pinned_ab.json batch_demo.log graph_ab.log soak.log; do
   [ -f $O/$f ] && cp $O/$f profiles/${TAG}_$f
 done
 [ -f $O/scale.json ] && cp $O/scale.json profiles/scale.json

@@ -25,3 +25,4 @@ timeout -k 10 400 python tests/tools/gpu_fuzz.py 6000 556 > $OUT/fuzz_6000_entry
 timeout -k 10 900 scripts/gpu_scale.sh ${TAG}_scale 96 400 > $OUT/scale.log 2>&1; echo "scale rc=$?"; cp profiles/scale.json $OUT/scale.json
 OAVIF_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 4 --steps 20 --warmup 5 > $OUT/bench_n4_gloo_bare.json 2> $OUT/bench_n4_gloo_bare.err; echo "bare bench n4 gloo rc=$?"; cut -c1-300 $OUT/bench_n4_gloo_bare.json
 OAVIF_BENCH_BACKEND=gloo timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_n2_gloo_torchrun.json 2> $OUT/bench_n2_gloo_torchrun.err; echo "torchrun bench n2 gloo rc=$?"; cut -c1-300 $OUT/bench_n2_gloo_torchrun.json
+timeout -k 10 400 python scripts/gpu_soak.py 150 > $OUT/soak.log 2>&1; echo "soak rc=$?"; tail -1 $OUT/soak.log

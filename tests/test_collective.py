@@ -189,7 +189,10 @@ def test_bench_line_carries_the_collective_record_through_rccl(hip_lib):
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     c = d["collective"]
     assert c["backend"] == "nccl" and c["world_size"] == 1 and c["distinct_devices"] == 1 and c["problems"] == [], c
-    assert "RCCL process group of one rank" in c["gathered_through"] and "error" not in c
+    # the N = 1 record goes the way an N > 1 job's does: store first, then the RCCL group (device tensors) as confirmation
+    assert c["gathered_through"].startswith("the rendezvous store") and "error" not in c
+    assert "confirmed by one all_gather over the job's process group (RCCL, device tensors)" in c["gathered_through"]
+    assert "RCCL process group of one rank" in c["gathered_through"]
     info = oavif_amd.query_device(0)
     r = c["ranks"][0]
     assert (r["rank"], r["device"], r["pci_bus_id"], r["numa_node"]) == (0, 0, info["pci_bus_id"], info["numa_node"])
