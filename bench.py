@@ -73,6 +73,23 @@ ALGO_BYTES_PER_PX_MARCH = 77.97
 ALGO_BYTES_PER_PX_BLUR = 31.99
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout, and this process is not the only writer of file descriptor 1: RCCL prints its
+    banner there (the GPU box exports NCCL_DEBUG=VERSION: five lines in front of the line on every run of round 6), child
+    processes inherit it.  From here on descriptor 1 IS descriptor 2 for everybody -- Python's own prints, C libraries,
+    children -- and the returned `emit(obj)` writes one JSON line to what stdout was.  Called once per rank, after the
+    self-launch decision (the supervisor relays its rank 0's stdout untouched)."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj) -> None:
+        sys.stdout.flush()
+        real.write(json.dumps(obj) + "\n")
+        real.flush()
+    return emit
+
+
 def usable_cores() -> int:
     """Host threads this process may really use (cgroup quota / affinity mask, capped at 32)."""
     from oavif_amd import hostinfo
@@ -470,6 +487,7 @@ def main() -> int:
     if launch.needs_self_launch(args.gpus):
         return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, label="bench.py")
 
+    emit = claim_stdout()   # stdout carries the JSON line and nothing else (RCCL's banner, stray prints -> stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -522,9 +540,9 @@ def main() -> int:
             coll["note"] = "a rehearsal: ranks share devices and the collectives run on CPU tensors; never a reported number"
         if rc_:
             if rank == 0:
-                print(json.dumps({"metric": "ssimulacra2_megapixels_per_sec", "value": None,
-                                  "error": "placement refused" if rc_ == collective.RC_REFUSED else "process group failed",
-                                  "n_gpus": world, "collective": coll}), flush=True)
+                emit({"metric": "ssimulacra2_megapixels_per_sec", "value": None,
+                      "error": "placement refused" if rc_ == collective.RC_REFUSED else "process group failed",
+                      "n_gpus": world, "collective": coll})
             return rc_
 
     w, h = args.width, args.height
@@ -1117,7 +1135,7 @@ def main() -> int:
                 out["cpu_baseline"] = cb
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)[:300], "kind": "port"}
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     for sc_ in scorers:
         sc_.close()

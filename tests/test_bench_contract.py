@@ -282,3 +282,24 @@ def test_the_collective_record_carries_each_ranks_runtime_environment():
     src = open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "oavif_amd", "batch.py")).read() + \
         open(os.path.join(ROOT, "oavif_amd", "launch.py")).read()
     assert 'environ.setdefault("HSA_' not in src and 'environ["HSA_' not in src
+
+
+def test_stdout_carries_the_json_line_and_nothing_else(tmp_path):
+    """The contract is ONE JSON line on stdout.  RCCL prints its banner on descriptor 1 (the GPU box exports
+    NCCL_DEBUG=VERSION) and children inherit it: after bench.claim_stdout() everybody else's descriptor 1 is stderr and only
+    `emit` reaches what stdout was."""
+    import subprocess
+    import sys
+    prog = ("import os, sys, json; sys.path.insert(0, %r); import bench\n"
+            "print('before the claim', flush=True)\n"
+            "emit = bench.claim_stdout()\n"
+            "print('python noise')\n"
+            "os.write(1, b'C library noise\\n')\n"
+            "os.system('echo child noise')\n"
+            "emit({'metric': 'm', 'value': 1.5})\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == 'before the claim\n{"metric": "m", "value": 1.5}\n'
+    for noise in ("python noise", "C library noise", "child noise"):
+        assert noise in r.stderr
+    assert "torch" not in r.stderr   # importing bench.py pulls in neither torch nor a GPU
